@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: n-qubit QFT gate application on MI355X.
+
+Metric (BASELINE.json): gate-applies/sec + achieved HBM GB/s, 30-qubit QFT,
+complex128, one GPU.  A "step" is one pass of the hot path over one batch: the
+full 465-gate stream of qc.qft on 30 qubits (src/lib/circuit.py:320-328), every
+gate submitted through the C-ABI (qh_apply1 / qh_applyc), state resident in HBM.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: launched by torch.distributed.run, one rank per GPU; the state is
+   sharded by its top log2(N) index bits, weak scaling: 2^30 amplitudes/GPU.)
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=5)
+  ap.add_argument('--warmup', type=int, default=1)
+  ap.add_argument('--qubits', type=int, default=0, help='default 30 + log2(gpus)')
+  ap.add_argument('--fusion', type=int, default=-1, help='0 per-gate kernels, 1 fused sweeps (default)')
+  ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--cpu-qubits', type=int, default=30)
+  ap.add_argument('--cpu-gates', type=int, default=8, help='gates of the stream timed on the CPU')
+  return ap.parse_args()
+
+
+def class_pass(st, ops, g8, sel, reps):
+  """Replay only the gates selected by `sel`, bracketed by HIP events on the
+  engine's stream; returns (avg ms per kernel launch, launches, alg bytes/launch)."""
+  st.sync()
+  st.reset_stats()
+  st.timer_begin()
+  for _ in range(reps):
+    st.run_stream(ops[sel], g8[sel])
+  ms = st.timer_end()
+  s = st.stats()
+  launches = max(1, s['kernels_launched'])
+  return ms / launches, launches // reps, s['bytes_swept'] / launches, s['bytes_algorithmic'] / launches
+
+
+def cpu_baseline(args, ops, g8):
+  """Reference xgates.cc build (oracle/_ref) if it travelled, else our C port,
+  single thread, on a bounded sample of the same stream."""
+  from tests import oracle_lib
+  n = args.cpu_qubits
+  psi = None
+  while psi is None and n >= 24:
+    try:
+      psi = np.zeros(1 << n, dtype=np.complex128)
+      psi[0x2CB9A5E3 & ((1 << n) - 1)] = 1.0
+    except MemoryError:
+      n -= 2
+  full = len(ops)
+  # same stream shape at n qubits
+  from qcc_amd import workloads
+  o, g = workloads.qft_stream(range(n)).arrays()
+  k = max(1, args.cpu_gates)
+  pick = np.unique(np.linspace(0, len(o) - 1, k).astype(int))
+  xg = oracle_lib.load_ref_xgates()
+  kind = 'reference' if xg is not None else 'port'
+  gc = np.ascontiguousarray(g).view(np.complex128).reshape(-1, 4)
+  # warm the pages with one H so that first-touch cost is not billed to the gate
+  if xg is not None:
+    xg.apply1(psi, gc[0], n, n - 1, 128)
+  orc = oracle_lib.load(fast=True) if xg is None else None
+  if orc is not None:
+    orc.apply1(psi, gc[0], n, n - 1)
+  t0 = time.perf_counter()
+  for i in pick:
+    c, t = int(o[i, 0]), int(o[i, 1])
+    if xg is not None:
+      if c == workloads.NO_CTL:
+        xg.apply1(psi, gc[i], n, t, 128)
+      else:
+        xg.applyc(psi, gc[i], n, c, t, 128)
+    else:
+      if c == workloads.NO_CTL:
+        orc.apply1(psi, gc[i], n, t)
+      else:
+        orc.applyc(psi, gc[i], n, c, t)
+  dt = time.perf_counter() - t0
+  rate = len(pick) / dt
+  # scale to the benchmark's state size: cost per gate is linear in 2^n
+  scale = 2.0 ** (n - args.qubits_shard)
+  return {
+      'value': rate * scale, 'unit': 'gate-applies/s', 'cores': 1, 'kind': kind,
+      'sample': (f'{len(pick)} gates (indices {pick.tolist()}) of the {len(o)}-gate {n}-qubit QFT stream, '
+                 f'complex128, single thread, {dt:.1f} s'
+                 + ('' if n == args.qubits_shard else f'; scaled x{scale:g} to 2^{args.qubits_shard} amplitudes')
+                 + (' ; reference src/lib/xgates.cc built -O3 -ffast-math by oracle/Makefile'
+                    if kind == 'reference' else ' ; oracle/xgates_oracle.c -O3 -march=native')),
+      'host_cpus': os.cpu_count(),
+  }
+
+
+def main():
+  args = parse()
+  rank = int(os.environ.get('RANK', '0'))
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  if world != args.gpus:
+    if world == 1 and args.gpus > 1:
+      raise SystemExit('bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)')
+  from qcc_amd import device, native, workloads
+  if native.device_count() < 1:
+    raise SystemExit('bench.py: no HIP device visible; the engine has no CPU fallback')
+  gbits = int(math.log2(world))
+  assert 1 << gbits == world, 'number of GPUs must be a power of two'
+  n = args.qubits or (30 + gbits)
+  nloc = n - gbits
+  args.qubits_shard = nloc
+  fusion = args.fusion if args.fusion >= 0 else native.QH_FUSE_SWEEP
+
+  dist = None
+  if world > 1:
+    from qcc_amd import sharded
+    eng = sharded.ShardedState(n, fusion=fusion, local_rank=local_rank)
+    dist = eng.dist
+  else:
+    eng = device.DeviceState(n, 128, device=local_rank, fusion=fusion)
+
+  ops, g8 = workloads.qft_stream(range(n)).arrays()
+  ngates = len(ops)
+  x = 0x2CB9A5E3 & ((1 << n) - 1)
+  eng.init_basis(x)
+  for _ in range(args.warmup):
+    eng.run_stream(ops, g8)
+  eng.sync()
+  eng.reset_stats()
+  if dist is not None:
+    dist.barrier()
+  t0 = time.perf_counter()
+  eng.timer_begin()
+  for _ in range(args.steps):
+    eng.run_stream(ops, g8)
+  ev_ms = eng.timer_end()  # flushes + waits for the stream
+  eng.sync()
+  if dist is not None:
+    dist.barrier()
+  wall = time.perf_counter() - t0
+  if dist is not None:
+    import torch
+    t = torch.tensor([wall], dtype=torch.float64, device='cuda')
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall = float(t.item())
+  stats = eng.stats()
+
+  # parity guard inside the bench: closed form on sampled amplitudes after the
+  # first full QFT is checked in tests; here we check the norm (cheap, device-side)
+  norm2 = eng.norm2_global() if world > 1 else eng.norm2()
+
+  out = None
+  if rank == 0:
+    steps = args.steps
+    shard_units = world  # one gate on a 2^(30+g) state = 2^g shard-gate-applies of 2^30
+    value = ngates * steps * shard_units / wall
+    launches = max(1, stats['kernels_launched'])
+    # ---- roofline of the dominant kernel --------------------------------------
+    if world == 1:
+      if fusion == native.QH_FUSE_OFF:
+        is_ctl = ops[:, 0] != workloads.NO_CTL
+        ms_d, n_d, swept_d, alg_d = class_pass(eng, ops, g8, is_ctl, 1)
+        ms_p, n_p, swept_p, alg_p = class_pass(eng, ops, g8, ~is_ctl, 1)
+        classes = {'k_diag (CU1, S/2 per launch)': (ms_d, n_d, alg_d), 'k_pair (H, 2S per launch)': (ms_p, n_p, alg_p)}
+        name = max(classes, key=lambda k: classes[k][0] * classes[k][1])
+        ms_l, n_l, bytes_l = classes[name]
+        other = {k: {'avg_ms': v[0], 'launches_per_step': v[1], 'GBps': v[2] / v[0] / 1e6} for k, v in classes.items()}
+      else:
+        name = 'k_sweep (fused register-tile sweep, read S + write S per launch)'
+        ms_l = ev_ms / launches
+        bytes_l = stats['bytes_swept'] / launches
+        other = {}
+      achieved = bytes_l / (ms_l * 1e-3) / 1e9
+      roofline = {'bound': 'hbm', 'kernel': name, 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                  'frac': achieved / HBM_PEAK_GBPS, 'traffic': None, 'avg_launch_ms': ms_l,
+                  'bytes_per_launch': bytes_l, 'classes': other}
+    else:
+      roofline = {'bound': 'hbm', 'achieved': stats['bytes_swept'] / (ev_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBPS,
+                  'unit': 'GB/s', 'frac': stats['bytes_swept'] / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                  'traffic': None, 'note': 'per-GPU bytes swept / event time of rank 0 (includes exchange waits)'}
+    out = {
+        'metric': 'gate-applies/sec (30-qubit-shard units), QFT', 'value': value, 'unit': 'gate-applies/s',
+        'n_gpus': world, 'steps': steps, 'warmup': args.warmup, 'ms_per_step': wall / steps * 1e3,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+        'config': {'workload': f'{n}-qubit QFT complex128, {ngates} gates/step (qc.qft order), '
+                               f'basis-state input, state resident in HBM, 2^{nloc} amplitudes per GPU',
+                   'qubits': n, 'gates_per_step': ngates, 'fusion': fusion,
+                   'sharding': 'none' if world == 1 else f'top {gbits} index bits across {world} GPUs'},
+        'whole_state_gate_applies_per_s': ngates * steps / wall,
+        'effective_GBps_algorithmic': stats['bytes_algorithmic'] / wall / 1e9,
+        'hbm_GBps_swept': stats['bytes_swept'] / wall / 1e9,
+        'kernels_per_step': stats['kernels_launched'] / steps,
+        'event_ms_per_step': ev_ms / steps, 'norm2': norm2,
+        'roofline': roofline,
+    }
+    if not args.no_cpu_baseline and world == 1:
+      out['cpu_baseline'] = cpu_baseline(args, ops, g8)
+      out['gpu_over_cpu'] = out['whole_state_gate_applies_per_s'] / out['cpu_baseline']['value']
+    print(json.dumps(out))
+  if world > 1:
+    eng.close()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+  main()

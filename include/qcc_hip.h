@@ -1,0 +1,160 @@
+/*
+ * qcc_hip.h -- C-ABI of the MI355X (gfx950) state-vector gate-application engine.
+ *
+ * This is the drop-in boundary for the hot path of qcc4cp/qcc: the two native
+ * entry points of the reference's `libxgates` CPython extension
+ *
+ *     apply1(psi, gate, nbits, tgt, bit_width)        src/lib/xgates.cc:89-107
+ *     applyc(psi, gate, nbits, ctl, tgt, bit_width)   src/lib/xgates.cc:126-145
+ *
+ * (templates apply1<> :23-41 and applyc<> :45-67; only callers are
+ * qc.apply1/qc.applyc, src/lib/circuit.py:180-215).  Everything here is plain
+ * C: opaque handle, raw pointers, sizes and ints.  No torch / numpy / Python
+ * types cross this boundary.  INTEGRATION.md shows the binding a maintainer of
+ * the reference adds (a `libxgates` module over ctypes).
+ *
+ * Conventions kept from the reference
+ *   - amplitudes are interleaved (re,im), C-contiguous, length 2^nbits,
+ *     complex128 when bit_width==128, complex64 when bit_width==64
+ *     (src/lib/tensor.py:42-46); gates are 4 complex numbers, row-major
+ *     [a b c d] (xgates.cc:18-21), ALWAYS passed here as 8 doubles;
+ *   - qubit numbers in qh_apply1/qh_applyc/qh_host_* are the reference's
+ *     big-endian qubit indices: qubit q is index bit (nbits-1-q)
+ *     (xgates.cc:26,48-49);
+ *   - updates are in place.
+ * Deliberate differences
+ *   - 64-bit indices (reference: int, breaks at 31 qubits, xgates.cc:27,33);
+ *   - errors are returned as status codes + qh_last_error(), never exit()
+ *     (reference: exit(EXIT_FAILURE), xgates.cc:28-32);
+ *   - the state may live in HBM behind a handle across calls (the reference
+ *     borrows a host NumPy buffer per call); qh_host_apply1/applyc keep the
+ *     borrow-a-host-buffer contract for literal drop-in use.
+ *
+ * Threading: one host thread per handle.  Work is asynchronous on the handle's
+ * HIP stream; qh_sync() waits.  All readers synchronise internally.
+ */
+#ifndef QCC_HIP_H_
+#define QCC_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct qh_state_s *qh_handle;
+
+/* status codes */
+#define QH_OK 0
+#define QH_ERR_BAD_QUBIT 1      /* qubit / bit position out of range            */
+#define QH_ERR_SAME_QUBIT 2     /* control == target                            */
+#define QH_ERR_BAD_DTYPE 3      /* bit_width not 64 / 128                       */
+#define QH_ERR_HIP 4            /* a HIP runtime call failed (see last_error)   */
+#define QH_ERR_ARG 5            /* NULL pointer, bad size, bad handle           */
+#define QH_ERR_NOMEM 6          /* device allocation failed                     */
+#define QH_ERR_NO_DEVICE 7      /* no gfx950 device visible                     */
+#define QH_ERR_NONLOCAL 8       /* non-diagonal gate targets a bit held by the
+                                   shard index: exchange first (qh_remap_swap)  */
+
+/* fusion levels for qh_set_fusion */
+#define QH_FUSE_OFF 0           /* one kernel per gate, launched immediately    */
+#define QH_FUSE_SWEEP 1         /* queue gates, plan register-tile sweeps       */
+
+const char *qh_last_error(void);
+int qh_version(void);
+int qh_device_count(int *count);
+
+/* ---- state lifetime ----------------------------------------------------- */
+/* Allocate 2^nbits amplitudes in HBM on `device` (own HIP stream).           */
+int qh_create(int nbits, int bit_width, int device, qh_handle *out);
+/* Use caller-owned device memory / stream (e.g. a torch allocation and
+ * torch's current stream, passed as raw pointers).  stream may be NULL
+ * (engine creates its own).                                                  */
+int qh_attach(int nbits, int bit_width, int device, void *device_ptr,
+              void *hip_stream, qh_handle *out);
+/* Planner-only handle: no device, no memory.  Gates can be queued and the
+ * plan inspected with qh_plan_json (used by CPU-side tests).                 */
+int qh_create_dry(int nbits, int bit_width, qh_handle *out);
+int qh_destroy(qh_handle h);
+
+/* Multi-GPU sharding: this handle holds the 2^nbits amplitudes whose global
+ * index has high bits == shard_index, out of a 2^nbits_global state.  Gates
+ * are then addressed in GLOBAL qubit numbers / bit positions.               */
+int qh_set_shard(qh_handle h, int nbits_global, uint64_t shard_index);
+int qh_device_ptr(qh_handle h, void **ptr);
+int qh_stream(qh_handle h, void **stream);
+int qh_nbits(qh_handle h, int *nbits_local, int *nbits_global);
+
+/* ---- initialisation and host <-> device --------------------------------- */
+/* |index> in global logical index space (zero elsewhere).                    */
+int qh_init_basis(qh_handle h, uint64_t index);
+/* offset/count in amplitudes of the LOCAL shard, physical order.             */
+int qh_upload(qh_handle h, const void *host, uint64_t offset, uint64_t count);
+int qh_download(qh_handle h, void *host, uint64_t offset, uint64_t count);
+
+/* ---- the hot path -------------------------------------------------------- */
+/* Reference semantics (xgates.cc:23-41): 2x2 `gate` on qubit `tgt`.          */
+int qh_apply1(qh_handle h, int tgt, const double gate[8]);
+/* Reference semantics (xgates.cc:45-67): `gate` on `tgt` where qubit `ctl` is 1. */
+int qh_applyc(qh_handle h, int ctl, int tgt, const double gate[8]);
+/* Generalisation in LOGICAL bit positions (bit 0 = least significant index
+ * bit = reference qubit nbits-1): gate on bit `tgt_bit` for indices having
+ * all bits of `ctl_mask` set.  Used by the multi-GPU layer and by native
+ * multi-controlled gates.                                                    */
+int qh_apply_bits(qh_handle h, uint64_t ctl_mask, int tgt_bit,
+                  const double gate[8]);
+
+int qh_set_fusion(qh_handle h, int level);
+/* Launch everything queued (no-op with QH_FUSE_OFF).                         */
+int qh_flush(qh_handle h);
+/* qh_flush + wait for the stream.                                            */
+int qh_sync(qh_handle h);
+
+/* ---- logical -> physical bit map (global<->local qubit swaps) ----------- */
+/* Records that the DATA of physical bits a and b has been exchanged (by the
+ * communication layer for a>=nbits_local, or by qh_swap_local_bits).  Later
+ * gates are routed through the map; readers report physical indices, convert
+ * with qh_phys_to_logical.                                                   */
+int qh_remap_swap(qh_handle h, int phys_bit_a, int phys_bit_b);
+int qh_get_bitmap(qh_handle h, int32_t *phys_of_logical /* [nbits_global] */);
+int qh_phys_to_logical(qh_handle h, uint64_t phys_index, uint64_t *logical);
+int qh_logical_to_phys(qh_handle h, uint64_t logical_index, uint64_t *phys);
+
+/* ---- device-side readers (state.py:24-78) ------------------ */
+int qh_norm2(qh_handle h, double *out);                       /* sum |a|^2 of the shard */
+int qh_argmax(qh_handle h, uint64_t *phys_index, double *prob); /* max |a|^2 of the shard */
+int qh_prob_bit(qh_handle h, int logical_bit, double *p1);    /* sum |a|^2 with bit set (shard) */
+int qh_scale(qh_handle h, double re, double im);              /* a *= (re + i im) */
+/* Project on logical_bit == value (zero the rest); caller renormalises with qh_scale. */
+int qh_project_bit(qh_handle h, int logical_bit, int value);
+
+/* ---- measurement of the engine itself ----------------------------------- */
+typedef struct {
+  uint64_t gates_submitted;   /* qh_apply* calls accepted                      */
+  uint64_t kernels_launched;  /* gate/sweep kernels launched                   */
+  uint64_t sweeps;            /* fused sweep launches                          */
+  uint64_t bytes_algorithmic; /* minimal-touch bytes of the gates  */
+  uint64_t bytes_swept;       /* bytes the launched kernels had to move        */
+  uint64_t gates_noop;        /* gates skipped by shard-bit predicate          */
+} qh_stats;
+int qh_get_stats(qh_handle h, qh_stats *out);
+int qh_reset_stats(qh_handle h);
+/* hipEvent pair on the handle's stream.                                      */
+int qh_timer_begin(qh_handle h);
+int qh_timer_end(qh_handle h, float *milliseconds);
+/* JSON text of the sweeps the planner would launch for the current queue
+ * (does not launch or clear).  Returns bytes needed; writes at most cap.     */
+int qh_plan_json(qh_handle h, char *buf, uint64_t cap, uint64_t *needed);
+
+/* ---- literal drop-in on host buffers (what `libxgates` binds) ----------- */
+/* psi: host pointer to 2^nbits complex numbers of width bit_width, updated in
+ * place (H2D, kernel, D2H -- PCIe inclusive).  gate: 8 doubles.              */
+int qh_host_apply1(void *psi, const double gate[8], int nbits, int tgt,
+                   int bit_width);
+int qh_host_applyc(void *psi, const double gate[8], int nbits, int ctl, int tgt,
+                   int bit_width);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QCC_HIP_H_ */

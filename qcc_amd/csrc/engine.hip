@@ -1,0 +1,792 @@
+// engine.hip -- C-ABI (include/qcc_hip.h) of the MI355X gate-application engine.
+//
+// Replaces the reference's native hot path: apply1<>/applyc<> and their CPython
+// wrappers in /root/reference/src/lib/xgates.cc:23-145.  One handle owns (or
+// borrows) 2^nbits amplitudes in HBM plus a HIP stream; gates are either
+// launched one kernel each (QH_FUSE_OFF, kernels_gate.hip.h) or queued and
+// executed as fused register-tile sweeps (QH_FUSE_SWEEP, planner.h +
+// kernels_sweep.hip.h).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/qcc_hip.h"
+#include "kernels_gate.hip.h"
+#include "planner.h"
+#include "kernels_sweep.hip.h"
+
+namespace {
+
+thread_local std::string g_err = "";
+
+int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                  \
+  do {                                                                                 \
+    hipError_t e_ = (expr);                                                            \
+    if (e_ != hipSuccess)                                                              \
+      return fail(e_ == hipErrorOutOfMemory ? QH_ERR_NOMEM : QH_ERR_HIP, "%s: %s (%s:%d)", \
+                  #expr, hipGetErrorString(e_), __FILE__, __LINE__);                   \
+  } while (0)
+
+constexpr int kRedBlocks = 1024;
+
+}  // namespace
+
+struct qh_state_s {
+  int nloc = 0, nglob = 0, bw = 128, device = 0;
+  uint64_t shard = 0;
+  void *d_psi = nullptr;
+  bool owns_mem = false, owns_stream = false, dry = false;
+  hipStream_t stream = nullptr;
+  int fusion = QH_FUSE_OFF;
+  int perm[64];  // physical bit of logical bit
+  std::vector<qh::GateRec> queue;
+  qh_stats stats{};
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double *d_red = nullptr;     // kRedBlocks doubles
+  uint64_t *d_redi = nullptr;  // kRedBlocks u64
+  qh::SweepBuffers sweep;      // device/pinned op buffers for fused sweeps
+  uint64_t amp_bytes() const { return bw == 128 ? 16 : 8; }
+  uint64_t local_mask() const { return nloc >= 64 ? ~0ull : ((1ull << nloc) - 1ull); }
+};
+
+namespace {
+
+int grid_cap() {
+  static int cap = [] {
+    const char *s = getenv("QH_GRID_CAP");
+    return s ? atoi(s) : 0;
+  }();
+  return cap;
+}
+
+template <typename R> qh::Gate2<R> to_gate(const double g[8]) {
+  qh::Gate2<R> o;
+  o.g0r = (R)g[0]; o.g0i = (R)g[1]; o.g1r = (R)g[2]; o.g1i = (R)g[3];
+  o.g2r = (R)g[4]; o.g2i = (R)g[5]; o.g3r = (R)g[6]; o.g3i = (R)g[7];
+  return o;
+}
+
+qh::BitIns make_ins(uint64_t ones_mask, int zero_pos) {
+  qh::BitIns ins{};
+  ins.n = 0;
+  ins.ones = ones_mask;
+  for (int b = 0; b < 64; ++b) {
+    if (((ones_mask >> b) & 1ull) || b == zero_pos) ins.pos[ins.n++] = b;
+  }
+  return ins;
+}
+
+unsigned pick_grid(uint64_t nwork, int per_block) {
+  uint64_t blocks = (nwork + per_block - 1) / per_block;
+  if (blocks < 1) blocks = 1;
+  const int cap = grid_cap();
+  if (cap > 0 && blocks > (uint64_t)cap) blocks = cap;
+  if (blocks > 0x7fffffffull) blocks = 0x7fffffffull;
+  return (unsigned)blocks;
+}
+
+template <typename R>
+void launch_pair(qh_state_s *h, uint64_t nwork, int p, const qh::BitIns &ins, const double g[8]) {
+  using A = typename qh::AmpT<R>::type;
+  constexpr int U = 4;
+  const unsigned grid = pick_grid(nwork, 256 * U);
+  if (nwork % (256 * U) == 0)
+    hipLaunchKernelGGL((qh::k_pair<R, U, false>), dim3(grid), dim3(256), 0, h->stream,
+                       (A *)h->d_psi, nwork, p, ins, to_gate<R>(g));
+  else
+    hipLaunchKernelGGL((qh::k_pair<R, U, true>), dim3(grid), dim3(256), 0, h->stream,
+                       (A *)h->d_psi, nwork, p, ins, to_gate<R>(g));
+}
+
+template <typename R>
+void launch_diag(qh_state_s *h, uint64_t nwork, int sel, const qh::BitIns &ins, double f0r,
+                 double f0i, double f1r, double f1i) {
+  using A = typename qh::AmpT<R>::type;
+  constexpr int U = 4;
+  const unsigned grid = pick_grid(nwork, 256 * U);
+  if (nwork % (256 * U) == 0)
+    hipLaunchKernelGGL((qh::k_diag<R, U, false>), dim3(grid), dim3(256), 0, h->stream,
+                       (A *)h->d_psi, nwork, sel, ins, (R)f0r, (R)f0i, (R)f1r, (R)f1i);
+  else
+    hipLaunchKernelGGL((qh::k_diag<R, U, true>), dim3(grid), dim3(256), 0, h->stream,
+                       (A *)h->d_psi, nwork, sel, ins, (R)f0r, (R)f0i, (R)f1r, (R)f1i);
+}
+
+// One gate, physical bit positions, one kernel.  Returns QH_* status.
+int launch_single(qh_state_s *h, const qh::GateRec &r) {
+  const uint64_t cm_hi = r.ctl_mask >> h->nloc;
+  if ((h->shard & cm_hi) != cm_hi) {
+    h->stats.gates_noop++;
+    return QH_OK;
+  }
+  const uint64_t cm = r.ctl_mask & h->local_mask();
+  const int nc = __builtin_popcountll(cm);
+  if (nc + 1 > qh::kMaxIns) return fail(QH_ERR_ARG, "too many local control bits (%d)", nc);
+  const double *g = r.g;
+  const bool diag = qh::is_diag(g);
+  const uint64_t ab = h->amp_bytes();
+  if (r.tgt >= h->nloc) {
+    if (!diag)
+      return fail(QH_ERR_NONLOCAL,
+                  "non-diagonal gate targets physical bit %d held by the shard index "
+                  "(local bits: %d); exchange first",
+                  r.tgt, h->nloc);
+    const bool set = (h->shard >> (r.tgt - h->nloc)) & 1ull;
+    const double fr = set ? g[6] : g[0], fi = set ? g[7] : g[1];
+    if (fr == 1.0 && fi == 0.0) {
+      h->stats.gates_noop++;
+      return QH_OK;
+    }
+    const uint64_t nwork = 1ull << (h->nloc - nc);
+    if (!h->dry) {
+      const qh::BitIns ins = make_ins(cm, -1);
+      if (h->bw == 128) launch_diag<double>(h, nwork, -1, ins, 1, 0, fr, fi);
+      else launch_diag<float>(h, nwork, -1, ins, 1, 0, fr, fi);
+    }
+    h->stats.kernels_launched++;
+    h->stats.bytes_algorithmic += nwork * ab * 2;
+    h->stats.bytes_swept += nwork * ab * 2;
+    return QH_OK;
+  }
+  if (diag) {
+    const bool one_sided = (g[0] == 1.0 && g[1] == 0.0);
+    if (one_sided && g[6] == 1.0 && g[7] == 0.0) {
+      h->stats.gates_noop++;
+      return QH_OK;  // identity
+    }
+    if (one_sided) {
+      const uint64_t nwork = 1ull << (h->nloc - nc - 1);
+      if (!h->dry) {
+        const qh::BitIns ins = make_ins(cm | (1ull << r.tgt), -1);
+        if (h->bw == 128) launch_diag<double>(h, nwork, -1, ins, 1, 0, g[6], g[7]);
+        else launch_diag<float>(h, nwork, -1, ins, 1, 0, g[6], g[7]);
+      }
+      h->stats.bytes_algorithmic += nwork * ab * 2;
+      h->stats.bytes_swept += nwork * ab * 2;
+    } else {
+      const uint64_t nwork = 1ull << (h->nloc - nc);
+      if (!h->dry) {
+        const qh::BitIns ins = make_ins(cm, -1);
+        if (h->bw == 128) launch_diag<double>(h, nwork, r.tgt, ins, g[0], g[1], g[6], g[7]);
+        else launch_diag<float>(h, nwork, r.tgt, ins, g[0], g[1], g[6], g[7]);
+      }
+      h->stats.bytes_algorithmic += nwork * ab * 2;
+      h->stats.bytes_swept += nwork * ab * 2;
+    }
+    h->stats.kernels_launched++;
+    return QH_OK;
+  }
+  const uint64_t nwork = 1ull << (h->nloc - nc - 1);
+  if (!h->dry) {
+    const qh::BitIns ins = make_ins(cm, r.tgt);
+    if (h->bw == 128) launch_pair<double>(h, nwork, r.tgt, ins, g);
+    else launch_pair<float>(h, nwork, r.tgt, ins, g);
+  }
+  h->stats.kernels_launched++;
+  h->stats.bytes_algorithmic += nwork * 2 * ab * 2;
+  h->stats.bytes_swept += nwork * 2 * ab * 2;
+  return QH_OK;
+}
+
+int check_launch(qh_state_s *h) {
+  if (h->dry) return QH_OK;
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(QH_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
+  return QH_OK;
+}
+
+int flush_impl(qh_state_s *h) {
+  if (h->queue.empty()) return QH_OK;
+  int rc = QH_OK;
+  if (h->fusion == QH_FUSE_SWEEP && qh::sweep_supported(h->nloc)) {
+    rc = qh::run_fused(h->queue, h->nloc, h->shard, h->bw, h->d_psi, h->stream, h->dry,
+                       &h->sweep, &h->stats, &g_err);
+    if (rc == QH_OK) rc = check_launch(h);
+  } else {
+    for (const auto &r : h->queue) {
+      rc = launch_single(h, r);
+      if (rc) break;
+    }
+    if (rc == QH_OK) rc = check_launch(h);
+  }
+  h->queue.clear();
+  return rc;
+}
+
+int submit_phys(qh_state_s *h, uint64_t cmask, int tbit, const double g[8]) {
+  qh::GateRec r;
+  r.ctl_mask = cmask;
+  r.tgt = tbit;
+  memcpy(r.g, g, sizeof r.g);
+  if (h->fusion != QH_FUSE_OFF) {
+    // a non-diagonal gate on a shard bit can never be executed: report now.
+    if (tbit >= h->nloc && !qh::is_diag(g))
+      return fail(QH_ERR_NONLOCAL,
+                  "non-diagonal gate targets physical bit %d held by the shard index", tbit);
+    h->queue.push_back(r);
+    h->stats.gates_submitted++;
+    if (h->queue.size() >= 8192) return flush_impl(h);
+    return QH_OK;
+  }
+  int rc = launch_single(h, r);
+  if (rc == QH_OK) rc = check_launch(h);
+  if (rc == QH_OK) h->stats.gates_submitted++;
+  return rc;
+}
+
+int apply_logical(qh_state_s *h, uint64_t ctl_mask, int tgt_bit, const double g[8]) {
+  if (!h) return fail(QH_ERR_ARG, "null handle");
+  if (!g) return fail(QH_ERR_ARG, "null gate");
+  if (tgt_bit < 0 || tgt_bit >= h->nglob)
+    return fail(QH_ERR_BAD_QUBIT, "target bit %d out of range [0,%d)", tgt_bit, h->nglob);
+  if (h->nglob < 64 && (ctl_mask >> h->nglob))
+    return fail(QH_ERR_BAD_QUBIT, "control mask 0x%llx has bits >= %d",
+                (unsigned long long)ctl_mask, h->nglob);
+  if ((ctl_mask >> tgt_bit) & 1ull) return fail(QH_ERR_SAME_QUBIT, "control == target (bit %d)", tgt_bit);
+  uint64_t pm = 0;
+  for (int b = 0; b < h->nglob; ++b)
+    if ((ctl_mask >> b) & 1ull) pm |= 1ull << h->perm[b];
+  return submit_phys(h, pm, h->perm[tgt_bit], g);
+}
+
+// Reference control semantics incl. quirk Q7 (see oracle/xgates_oracle.c):
+// maps a reference control qubit number to a logical control bit, -1 = no-op,
+// -2 = error.
+int ref_ctl_bit(int nbits, int ctl, int tgt_bit) {
+  const long c = (long)nbits - (long)ctl - 1;
+  if (c < 0) return -2;
+  if (c < nbits) return (int)c;
+  const long b = c - nbits;  // bit b of the block base g
+  if (b > tgt_bit && b < nbits) return (int)b;
+  return -1;
+}
+
+int make_events(qh_state_s *h) {
+  if (!h->ev0) {
+    HIP_TRY(hipEventCreate(&h->ev0));
+    HIP_TRY(hipEventCreate(&h->ev1));
+  }
+  return QH_OK;
+}
+
+int common_init(qh_state_s *h) {
+  for (int b = 0; b < 64; ++b) h->perm[b] = b;
+  if (h->dry) return QH_OK;
+  HIP_TRY(hipMalloc(&h->d_red, kRedBlocks * sizeof(double)));
+  HIP_TRY(hipMalloc(&h->d_redi, kRedBlocks * sizeof(uint64_t)));
+  return QH_OK;
+}
+
+int check_args(int nbits, int bit_width) {
+  if (nbits < 1 || nbits > 40) return fail(QH_ERR_ARG, "nbits %d out of range [1,40]", nbits);
+  if (bit_width != 64 && bit_width != 128)
+    return fail(QH_ERR_BAD_DTYPE, "bit_width %d (want 64 or 128)", bit_width);
+  return QH_OK;
+}
+
+int select_device(int device) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(QH_ERR_NO_DEVICE, "no HIP device visible (%s); this engine has no CPU fallback",
+                e == hipSuccess ? "count=0" : hipGetErrorString(e));
+  if (device < 0 || device >= n) return fail(QH_ERR_ARG, "device %d of %d", device, n);
+  HIP_TRY(hipSetDevice(device));
+  return QH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *qh_last_error(void) { return g_err.c_str(); }
+int qh_version(void) { return 100; }
+
+int qh_device_count(int *count) {
+  if (!count) return fail(QH_ERR_ARG, "null");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  *count = (e == hipSuccess) ? n : 0;
+  return QH_OK;
+}
+
+int qh_create(int nbits, int bit_width, int device, qh_handle *out) {
+  if (!out) return fail(QH_ERR_ARG, "null out");
+  int rc = check_args(nbits, bit_width);
+  if (rc) return rc;
+  rc = select_device(device);
+  if (rc) return rc;
+  auto *h = new qh_state_s;
+  h->nloc = h->nglob = nbits;
+  h->bw = bit_width;
+  h->device = device;
+  const uint64_t bytes = (1ull << nbits) * h->amp_bytes();
+  hipError_t e = hipMalloc(&h->d_psi, bytes);
+  if (e != hipSuccess) {
+    delete h;
+    return fail(QH_ERR_NOMEM, "hipMalloc(%llu bytes) for %d qubits: %s", (unsigned long long)bytes,
+                nbits, hipGetErrorString(e));
+  }
+  h->owns_mem = true;
+  e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    (void)hipFree(h->d_psi);
+    delete h;
+    return fail(QH_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+  }
+  h->owns_stream = true;
+  rc = common_init(h);
+  if (rc) {
+    qh_destroy(h);
+    return rc;
+  }
+  *out = h;
+  return QH_OK;
+}
+
+int qh_attach(int nbits, int bit_width, int device, void *device_ptr, void *hip_stream,
+              qh_handle *out) {
+  if (!out || !device_ptr) return fail(QH_ERR_ARG, "null pointer");
+  int rc = check_args(nbits, bit_width);
+  if (rc) return rc;
+  rc = select_device(device);
+  if (rc) return rc;
+  auto *h = new qh_state_s;
+  h->nloc = h->nglob = nbits;
+  h->bw = bit_width;
+  h->device = device;
+  h->d_psi = device_ptr;
+  if (hip_stream) {
+    h->stream = (hipStream_t)hip_stream;
+  } else {
+    hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      delete h;
+      return fail(QH_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    h->owns_stream = true;
+  }
+  rc = common_init(h);
+  if (rc) {
+    qh_destroy(h);
+    return rc;
+  }
+  *out = h;
+  return QH_OK;
+}
+
+int qh_create_dry(int nbits, int bit_width, qh_handle *out) {
+  if (!out) return fail(QH_ERR_ARG, "null out");
+  int rc = check_args(nbits, bit_width);
+  if (rc) return rc;
+  auto *h = new qh_state_s;
+  h->nloc = h->nglob = nbits;
+  h->bw = bit_width;
+  h->dry = true;
+  common_init(h);
+  *out = h;
+  return QH_OK;
+}
+
+int qh_destroy(qh_handle h) {
+  if (!h) return QH_OK;
+  if (!h->dry) {
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    qh::free_sweep_buffers(&h->sweep);
+    if (h->d_red) (void)hipFree(h->d_red);
+    if (h->d_redi) (void)hipFree(h->d_redi);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->owns_mem && h->d_psi) (void)hipFree(h->d_psi);
+    if (h->owns_stream && h->stream) (void)hipStreamDestroy(h->stream);
+  }
+  delete h;
+  return QH_OK;
+}
+
+int qh_set_shard(qh_handle h, int nbits_global, uint64_t shard_index) {
+  if (!h) return fail(QH_ERR_ARG, "null handle");
+  if (nbits_global < h->nloc || nbits_global > 62)
+    return fail(QH_ERR_ARG, "nbits_global %d < local %d", nbits_global, h->nloc);
+  if (nbits_global - h->nloc < 64 && (shard_index >> (nbits_global - h->nloc)) != 0)
+    return fail(QH_ERR_ARG, "shard index %llu does not fit %d shard bits",
+                (unsigned long long)shard_index, nbits_global - h->nloc);
+  h->nglob = nbits_global;
+  h->shard = shard_index;
+  return QH_OK;
+}
+
+int qh_device_ptr(qh_handle h, void **ptr) {
+  if (!h || !ptr) return fail(QH_ERR_ARG, "null");
+  *ptr = h->d_psi;
+  return QH_OK;
+}
+int qh_stream(qh_handle h, void **stream) {
+  if (!h || !stream) return fail(QH_ERR_ARG, "null");
+  *stream = (void *)h->stream;
+  return QH_OK;
+}
+int qh_nbits(qh_handle h, int *nl, int *ng) {
+  if (!h) return fail(QH_ERR_ARG, "null");
+  if (nl) *nl = h->nloc;
+  if (ng) *ng = h->nglob;
+  return QH_OK;
+}
+
+int qh_logical_to_phys(qh_handle h, uint64_t logical, uint64_t *phys) {
+  if (!h || !phys) return fail(QH_ERR_ARG, "null");
+  uint64_t p = 0;
+  for (int b = 0; b < h->nglob; ++b)
+    if ((logical >> b) & 1ull) p |= 1ull << h->perm[b];
+  *phys = p;
+  return QH_OK;
+}
+int qh_phys_to_logical(qh_handle h, uint64_t phys, uint64_t *logical) {
+  if (!h || !logical) return fail(QH_ERR_ARG, "null");
+  uint64_t l = 0;
+  for (int b = 0; b < h->nglob; ++b)
+    if ((phys >> h->perm[b]) & 1ull) l |= 1ull << b;
+  *logical = l;
+  return QH_OK;
+}
+int qh_get_bitmap(qh_handle h, int32_t *out) {
+  if (!h || !out) return fail(QH_ERR_ARG, "null");
+  for (int b = 0; b < h->nglob; ++b) out[b] = h->perm[b];
+  return QH_OK;
+}
+int qh_remap_swap(qh_handle h, int a, int b) {
+  if (!h) return fail(QH_ERR_ARG, "null");
+  if (a < 0 || b < 0 || a >= h->nglob || b >= h->nglob)
+    return fail(QH_ERR_BAD_QUBIT, "physical bits %d,%d out of range", a, b);
+  int rc = flush_impl(h);
+  if (rc) return rc;
+  int la = -1, lb = -1;
+  for (int l = 0; l < h->nglob; ++l) {
+    if (h->perm[l] == a) la = l;
+    if (h->perm[l] == b) lb = l;
+  }
+  std::swap(h->perm[la], h->perm[lb]);
+  return QH_OK;
+}
+
+int qh_init_basis(qh_handle h, uint64_t index) {
+  if (!h) return fail(QH_ERR_ARG, "null handle");
+  if (h->nglob < 64 && (index >> h->nglob)) return fail(QH_ERR_ARG, "basis index out of range");
+  h->queue.clear();
+  if (h->dry) return QH_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  uint64_t phys;
+  qh_logical_to_phys(h, index, &phys);
+  HIP_TRY(hipMemsetAsync(h->d_psi, 0, (1ull << h->nloc) * h->amp_bytes(), h->stream));
+  if ((phys >> h->nloc) == h->shard) {
+    const uint64_t li = phys & h->local_mask();
+    if (h->bw == 128)
+      hipLaunchKernelGGL(qh::k_set_one<double>, dim3(1), dim3(1), 0, h->stream, (double2 *)h->d_psi, li);
+    else
+      hipLaunchKernelGGL(qh::k_set_one<float>, dim3(1), dim3(1), 0, h->stream, (float2 *)h->d_psi, li);
+  }
+  return check_launch(h);
+}
+
+int qh_upload(qh_handle h, const void *host, uint64_t offset, uint64_t count) {
+  if (!h || !host || h->dry) return fail(QH_ERR_ARG, "null/dry");
+  if (offset + count > (1ull << h->nloc)) return fail(QH_ERR_ARG, "upload range out of bounds");
+  int rc = flush_impl(h);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipMemcpyAsync((char *)h->d_psi + offset * h->amp_bytes(), host, count * h->amp_bytes(),
+                         hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return QH_OK;
+}
+
+int qh_download(qh_handle h, void *host, uint64_t offset, uint64_t count) {
+  if (!h || !host || h->dry) return fail(QH_ERR_ARG, "null/dry");
+  if (offset + count > (1ull << h->nloc)) return fail(QH_ERR_ARG, "download range out of bounds");
+  int rc = flush_impl(h);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipMemcpyAsync(host, (const char *)h->d_psi + offset * h->amp_bytes(),
+                         count * h->amp_bytes(), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return QH_OK;
+}
+
+int qh_apply_bits(qh_handle h, uint64_t ctl_mask, int tgt_bit, const double gate[8]) {
+  return apply_logical(h, ctl_mask, tgt_bit, gate);
+}
+
+int qh_apply1(qh_handle h, int tgt, const double gate[8]) {
+  if (!h) return fail(QH_ERR_ARG, "null handle");
+  const int p = h->nglob - tgt - 1;  // xgates.cc:26
+  if (p < 0 || p >= h->nglob)
+    return fail(QH_ERR_BAD_QUBIT, "apply1: qubit %d out of range for %d qubits", tgt, h->nglob);
+  return apply_logical(h, 0, p, gate);
+}
+
+int qh_applyc(qh_handle h, int ctl, int tgt, const double gate[8]) {
+  if (!h) return fail(QH_ERR_ARG, "null handle");
+  const int p = h->nglob - tgt - 1;  // xgates.cc:48
+  if (p < 0 || p >= h->nglob)
+    return fail(QH_ERR_BAD_QUBIT, "applyc: target qubit %d out of range for %d qubits", tgt, h->nglob);
+  const int c = ref_ctl_bit(h->nglob, ctl, p);  // xgates.cc:49,58-59
+  if (c == -2)
+    return fail(QH_ERR_BAD_QUBIT, "applyc: control qubit %d out of range for %d qubits", ctl, h->nglob);
+  if (c == -1) {  // out-of-range (negative) control whose predicate is never true
+    h->stats.gates_submitted++;
+    h->stats.gates_noop++;
+    return QH_OK;
+  }
+  if (c == p) return fail(QH_ERR_SAME_QUBIT, "applyc: control == target (qubit %d)", tgt);
+  return apply_logical(h, 1ull << c, p, gate);
+}
+
+int qh_set_fusion(qh_handle h, int level) {
+  if (!h) return fail(QH_ERR_ARG, "null handle");
+  if (level != QH_FUSE_OFF && level != QH_FUSE_SWEEP) return fail(QH_ERR_ARG, "fusion level %d", level);
+  int rc = flush_impl(h);
+  h->fusion = level;
+  return rc;
+}
+
+int qh_flush(qh_handle h) {
+  if (!h) return fail(QH_ERR_ARG, "null handle");
+  if (!h->dry) HIP_TRY(hipSetDevice(h->device));
+  return flush_impl(h);
+}
+
+int qh_sync(qh_handle h) {
+  if (!h) return fail(QH_ERR_ARG, "null handle");
+  if (h->dry) {
+    return flush_impl(h);
+  }
+  HIP_TRY(hipSetDevice(h->device));
+  int rc = flush_impl(h);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return QH_OK;
+}
+
+int qh_norm2(qh_handle h, double *out) {
+  if (!h || !out || h->dry) return fail(QH_ERR_ARG, "null/dry");
+  HIP_TRY(hipSetDevice(h->device));
+  int rc = flush_impl(h);
+  if (rc) return rc;
+  HIP_TRY(hipMemsetAsync(h->d_red, 0, sizeof(double), h->stream));
+  const uint64_t n = 1ull << h->nloc;
+  const unsigned grid = (unsigned)std::min<uint64_t>((n + 255) / 256, 4096);
+  if (h->bw == 128)
+    hipLaunchKernelGGL(qh::k_norm2<double>, dim3(grid), dim3(256), 0, h->stream,
+                       (const double2 *)h->d_psi, n, 0ull, h->d_red);
+  else
+    hipLaunchKernelGGL(qh::k_norm2<float>, dim3(grid), dim3(256), 0, h->stream,
+                       (const float2 *)h->d_psi, n, 0ull, h->d_red);
+  HIP_TRY(hipMemcpyAsync(out, h->d_red, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return QH_OK;
+}
+
+int qh_prob_bit(qh_handle h, int logical_bit, double *p1) {
+  if (!h || !p1 || h->dry) return fail(QH_ERR_ARG, "null/dry");
+  if (logical_bit < 0 || logical_bit >= h->nglob) return fail(QH_ERR_BAD_QUBIT, "bit %d", logical_bit);
+  HIP_TRY(hipSetDevice(h->device));
+  int rc = flush_impl(h);
+  if (rc) return rc;
+  const int pb = h->perm[logical_bit];
+  uint64_t mask = 0;
+  if (pb >= h->nloc) {
+    if (!((h->shard >> (pb - h->nloc)) & 1ull)) {
+      *p1 = 0.0;
+      return QH_OK;
+    }
+  } else {
+    mask = 1ull << pb;
+  }
+  HIP_TRY(hipMemsetAsync(h->d_red, 0, sizeof(double), h->stream));
+  const uint64_t n = 1ull << h->nloc;
+  const unsigned grid = (unsigned)std::min<uint64_t>((n + 255) / 256, 4096);
+  if (h->bw == 128)
+    hipLaunchKernelGGL(qh::k_norm2<double>, dim3(grid), dim3(256), 0, h->stream,
+                       (const double2 *)h->d_psi, n, mask, h->d_red);
+  else
+    hipLaunchKernelGGL(qh::k_norm2<float>, dim3(grid), dim3(256), 0, h->stream,
+                       (const float2 *)h->d_psi, n, mask, h->d_red);
+  HIP_TRY(hipMemcpyAsync(p1, h->d_red, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return QH_OK;
+}
+
+int qh_argmax(qh_handle h, uint64_t *phys_index, double *prob) {
+  if (!h || !phys_index || !prob || h->dry) return fail(QH_ERR_ARG, "null/dry");
+  HIP_TRY(hipSetDevice(h->device));
+  int rc = flush_impl(h);
+  if (rc) return rc;
+  const uint64_t n = 1ull << h->nloc;
+  const unsigned grid = (unsigned)std::min<uint64_t>((n + 255) / 256, kRedBlocks);
+  if (h->bw == 128)
+    hipLaunchKernelGGL(qh::k_argmax<double>, dim3(grid), dim3(256), 0, h->stream,
+                       (const double2 *)h->d_psi, n, h->d_red, h->d_redi);
+  else
+    hipLaunchKernelGGL(qh::k_argmax<float>, dim3(grid), dim3(256), 0, h->stream,
+                       (const float2 *)h->d_psi, n, h->d_red, h->d_redi);
+  std::vector<double> bp(grid);
+  std::vector<uint64_t> bi(grid);
+  HIP_TRY(hipMemcpyAsync(bp.data(), h->d_red, grid * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(bi.data(), h->d_redi, grid * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  double best = -1.0;
+  uint64_t idx = 0;
+  for (unsigned k = 0; k < grid; ++k)
+    if (bp[k] > best || (bp[k] == best && bi[k] < idx)) {
+      best = bp[k];
+      idx = bi[k];
+    }
+  *phys_index = (h->shard << h->nloc) | idx;
+  *prob = best;
+  return QH_OK;
+}
+
+int qh_scale(qh_handle h, double re, double im) {
+  if (!h || h->dry) return fail(QH_ERR_ARG, "null/dry");
+  HIP_TRY(hipSetDevice(h->device));
+  int rc = flush_impl(h);
+  if (rc) return rc;
+  qh::BitIns ins{};
+  const uint64_t nwork = 1ull << h->nloc;
+  if (h->bw == 128) launch_diag<double>(h, nwork, -1, ins, 1, 0, re, im);
+  else launch_diag<float>(h, nwork, -1, ins, 1, 0, re, im);
+  return check_launch(h);
+}
+
+int qh_project_bit(qh_handle h, int logical_bit, int value) {
+  if (!h || h->dry) return fail(QH_ERR_ARG, "null/dry");
+  if (logical_bit < 0 || logical_bit >= h->nglob) return fail(QH_ERR_BAD_QUBIT, "bit %d", logical_bit);
+  HIP_TRY(hipSetDevice(h->device));
+  int rc = flush_impl(h);
+  if (rc) return rc;
+  const int pb = h->perm[logical_bit];
+  value = value ? 1 : 0;
+  if (pb >= h->nloc) {
+    if ((int)((h->shard >> (pb - h->nloc)) & 1ull) != value)
+      HIP_TRY(hipMemsetAsync(h->d_psi, 0, (1ull << h->nloc) * h->amp_bytes(), h->stream));
+    return QH_OK;
+  }
+  qh::BitIns ins = make_ins(value ? 0ull : (1ull << pb), value ? pb : -1);
+  const uint64_t nwork = 1ull << (h->nloc - 1);
+  const unsigned grid = (unsigned)std::min<uint64_t>((nwork + 255) / 256, 1u << 20);
+  if (h->bw == 128)
+    hipLaunchKernelGGL(qh::k_project<double>, dim3(grid), dim3(256), 0, h->stream, (double2 *)h->d_psi, nwork, ins);
+  else
+    hipLaunchKernelGGL(qh::k_project<float>, dim3(grid), dim3(256), 0, h->stream, (float2 *)h->d_psi, nwork, ins);
+  return check_launch(h);
+}
+
+int qh_get_stats(qh_handle h, qh_stats *out) {
+  if (!h || !out) return fail(QH_ERR_ARG, "null");
+  *out = h->stats;
+  return QH_OK;
+}
+int qh_reset_stats(qh_handle h) {
+  if (!h) return fail(QH_ERR_ARG, "null");
+  h->stats = qh_stats{};
+  return QH_OK;
+}
+
+int qh_timer_begin(qh_handle h) {
+  if (!h || h->dry) return fail(QH_ERR_ARG, "null/dry");
+  HIP_TRY(hipSetDevice(h->device));
+  int rc = flush_impl(h);
+  if (rc) return rc;
+  rc = make_events(h);
+  if (rc) return rc;
+  HIP_TRY(hipEventRecord(h->ev0, h->stream));
+  return QH_OK;
+}
+int qh_timer_end(qh_handle h, float *ms) {
+  if (!h || !ms || h->dry) return fail(QH_ERR_ARG, "null/dry");
+  if (!h->ev0) return fail(QH_ERR_ARG, "qh_timer_end without qh_timer_begin");
+  HIP_TRY(hipSetDevice(h->device));
+  int rc = flush_impl(h);
+  if (rc) return rc;
+  HIP_TRY(hipEventRecord(h->ev1, h->stream));
+  HIP_TRY(hipEventSynchronize(h->ev1));
+  HIP_TRY(hipEventElapsedTime(ms, h->ev0, h->ev1));
+  return QH_OK;
+}
+
+int qh_plan_json(qh_handle h, char *buf, uint64_t cap, uint64_t *needed) {
+  if (!h) return fail(QH_ERR_ARG, "null");
+  std::string s = qh::plan_to_json(h->queue, h->nloc, h->shard);
+  if (needed) *needed = s.size() + 1;
+  if (buf && cap) {
+    const uint64_t n = std::min<uint64_t>(cap - 1, s.size());
+    memcpy(buf, s.data(), n);
+    buf[n] = 0;
+  }
+  return QH_OK;
+}
+
+// ---- literal drop-in on host buffers ------------------------------------------
+static qh_handle g_host_h = nullptr;
+
+static int host_handle(int nbits, int bw, qh_handle *out) {
+  if (g_host_h && (g_host_h->nloc != nbits || g_host_h->bw != bw)) {
+    qh_destroy(g_host_h);
+    g_host_h = nullptr;
+  }
+  if (!g_host_h) {
+    int rc = qh_create(nbits, bw, 0, &g_host_h);
+    if (rc) return rc;
+  }
+  *out = g_host_h;
+  return QH_OK;
+}
+
+int qh_host_apply1(void *psi, const double gate[8], int nbits, int tgt, int bit_width) {
+  if (!psi || !gate) return fail(QH_ERR_ARG, "null pointer");
+  int rc = check_args(nbits, bit_width);
+  if (rc) return rc;
+  if (tgt < 0 || tgt >= nbits) return fail(QH_ERR_BAD_QUBIT, "apply1: qubit %d out of range for %d qubits", tgt, nbits);
+  qh_handle h;
+  rc = host_handle(nbits, bit_width, &h);
+  if (rc) return rc;
+  if ((rc = qh_upload(h, psi, 0, 1ull << nbits))) return rc;
+  if ((rc = qh_apply1(h, tgt, gate))) return rc;
+  return qh_download(h, psi, 0, 1ull << nbits);
+}
+
+int qh_host_applyc(void *psi, const double gate[8], int nbits, int ctl, int tgt, int bit_width) {
+  if (!psi || !gate) return fail(QH_ERR_ARG, "null pointer");
+  int rc = check_args(nbits, bit_width);
+  if (rc) return rc;
+  if (tgt < 0 || tgt >= nbits) return fail(QH_ERR_BAD_QUBIT, "applyc: qubit %d out of range for %d qubits", tgt, nbits);
+  const int c = ref_ctl_bit(nbits, ctl, nbits - tgt - 1);
+  if (c == -2) return fail(QH_ERR_BAD_QUBIT, "applyc: control qubit %d out of range for %d qubits", ctl, nbits);
+  if (c == -1) return QH_OK;  // predicate never true: the reference leaves psi untouched
+  qh_handle h;
+  rc = host_handle(nbits, bit_width, &h);
+  if (rc) return rc;
+  if ((rc = qh_upload(h, psi, 0, 1ull << nbits))) return rc;
+  if ((rc = qh_applyc(h, ctl, tgt, gate))) return rc;
+  return qh_download(h, psi, 0, 1ull << nbits);
+}
+
+}  // extern "C"

@@ -1,0 +1,224 @@
+// kernels_gate.hip.h -- one-gate-per-launch kernels for gfx950 (MI355X).
+//
+// These are the "unfused" kernels: each launch applies exactly one reference
+// gate application (apply1<> / applyc<>, /root/reference/src/lib/xgates.cc:23-67)
+// to the amplitudes resident in HBM.  They are pure streaming kernels:
+// arithmetic intensity is 28 flop per 64 B, far below the FP64 vector roof, so
+// the only roofline that matters is HBM bandwidth and the design rules are
+//   * every lane moves one 16-byte amplitude per load/store instruction
+//     (global_load_dwordx4 / global_store_dwordx4, 1 KiB per wave instruction);
+//   * untouched amplitudes are never read: control bits and the "bit set" half
+//     of a diagonal gate are folded into the index enumeration (bit insertion),
+//     so a CU1 moves S/2 bytes, not 2S;
+//   * U independent work items per thread are loaded before any is used, to
+//     keep >= 8 KiB of loads in flight per CU;
+//   * 64-bit index arithmetic throughout.
+//
+// Algorithmic (minimal-touch) bytes per launch, S = bytes of the local state:
+//   k_pair  no control: 2S      with c control bits: 2S / 2^c
+//   k_diag  one-sided (d0 == 1): S / 2^c   two-sided: 2S / 2^c
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace qh {
+
+constexpr int kMaxIns = 8;
+
+// Sorted (ascending) list of bit positions at which a bit is inserted into a
+// dense work-item counter to form an amplitude index; `ones` has the inserted
+// bits that are fixed to 1 (controls / "bit set" half), the rest are 0 (the
+// low element of a pair).
+struct BitIns {
+  int n;
+  int pos[kMaxIns];
+  uint64_t ones;
+};
+
+__device__ __forceinline__ uint64_t expand_index(uint64_t j, const BitIns &ins) {
+#pragma unroll
+  for (int k = 0; k < kMaxIns; ++k) {
+    if (k < ins.n) {
+      const uint64_t low = (1ull << ins.pos[k]) - 1ull;
+      j = ((j & ~low) << 1) | (j & low);
+    }
+  }
+  return j | ins.ones;
+}
+
+template <typename R> struct AmpT;
+template <> struct AmpT<double> { using type = double2; };
+template <> struct AmpT<float> { using type = float2; };
+
+template <typename R> struct Gate2 {
+  R g0r, g0i, g1r, g1i, g2r, g2i, g3r, g3i;
+};
+
+template <typename R, typename A>
+__device__ __forceinline__ void butterfly(const Gate2<R> &g, A &a, A &b) {
+  const R ar = a.x, ai = a.y, br = b.x, bi = b.y;
+  A t1, t2;
+  t1.x = (g.g0r * ar - g.g0i * ai) + (g.g1r * br - g.g1i * bi);
+  t1.y = (g.g0r * ai + g.g0i * ar) + (g.g1r * bi + g.g1i * br);
+  t2.x = (g.g2r * ar - g.g2i * ai) + (g.g3r * br - g.g3i * bi);
+  t2.y = (g.g2r * ai + g.g2i * ar) + (g.g3r * bi + g.g3i * br);
+  a = t1;
+  b = t2;
+}
+
+// Dense / anti-diagonal 2x2 on bit p.  Work item j (one per amplitude PAIR)
+// expands to the index of the pair's low element: a zero inserted at p, ones
+// inserted at the control bits.
+template <typename R, int U, bool GUARD>
+__global__ __launch_bounds__(256) void k_pair(typename AmpT<R>::type *__restrict__ psi,
+                                               uint64_t nwork, int p, BitIns ins,
+                                               Gate2<R> g) {
+  using A = typename AmpT<R>::type;
+  const uint64_t stride = (uint64_t)gridDim.x * (256ull * U);
+  const uint64_t q2 = 1ull << p;
+  for (uint64_t base = (uint64_t)blockIdx.x * (256ull * U) + threadIdx.x; base < nwork;
+       base += stride) {
+    A a[U], b[U];
+    uint64_t idx[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint64_t j = base + 256ull * u;
+      if (!GUARD || j < nwork) {
+        idx[u] = expand_index(j, ins);
+        a[u] = psi[idx[u]];
+        b[u] = psi[idx[u] | q2];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint64_t j = base + 256ull * u;
+      if (!GUARD || j < nwork) {
+        butterfly<R, A>(g, a[u], b[u]);
+        psi[idx[u]] = a[u];
+        psi[idx[u] | q2] = b[u];
+      }
+    }
+  }
+}
+
+// Diagonal gate: amp *= (bit sel of index set ? f1 : f0); sel < 0 means f1
+// always (one-sided gate: the enumeration already fixed the target bit to 1).
+template <typename R, int U, bool GUARD>
+__global__ __launch_bounds__(256) void k_diag(typename AmpT<R>::type *__restrict__ psi,
+                                               uint64_t nwork, int sel, BitIns ins, R f0r,
+                                               R f0i, R f1r, R f1i) {
+  using A = typename AmpT<R>::type;
+  const uint64_t stride = (uint64_t)gridDim.x * (256ull * U);
+  for (uint64_t base = (uint64_t)blockIdx.x * (256ull * U) + threadIdx.x; base < nwork;
+       base += stride) {
+    A a[U];
+    uint64_t idx[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint64_t j = base + 256ull * u;
+      if (!GUARD || j < nwork) {
+        idx[u] = expand_index(j, ins);
+        a[u] = psi[idx[u]];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint64_t j = base + 256ull * u;
+      if (!GUARD || j < nwork) {
+        const bool hi = sel < 0 || ((idx[u] >> sel) & 1ull);
+        const R fr = hi ? f1r : f0r, fi = hi ? f1i : f0i;
+        A t;
+        t.x = fr * a[u].x - fi * a[u].y;
+        t.y = fr * a[u].y + fi * a[u].x;
+        psi[idx[u]] = t;
+      }
+    }
+  }
+}
+
+// ---- initialisation ----------------------------------------------------------
+template <typename R>
+__global__ void k_set_one(typename AmpT<R>::type *psi, uint64_t index) {
+  typename AmpT<R>::type one;
+  one.x = (R)1;
+  one.y = (R)0;
+  psi[index] = one;
+}
+
+// ---- readers ----------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// out[0] += sum |a|^2 over indices having all bits of `mask` set (mask==0: all).
+template <typename R>
+__global__ __launch_bounds__(256) void k_norm2(const typename AmpT<R>::type *__restrict__ psi,
+                                                uint64_t n, uint64_t mask, double *out) {
+  __shared__ double part[4];
+  double acc = 0.0;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n;
+       i += (uint64_t)gridDim.x * 256) {
+    if ((i & mask) == mask) {
+      const auto a = psi[i];
+      acc += (double)a.x * (double)a.x + (double)a.y * (double)a.y;
+    }
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+}
+
+// per-block (max |a|^2, first index attaining it); host reduces the block list.
+template <typename R>
+__global__ __launch_bounds__(256) void k_argmax(const typename AmpT<R>::type *__restrict__ psi,
+                                                 uint64_t n, double *best_p,
+                                                 uint64_t *best_i) {
+  __shared__ double sp[256];
+  __shared__ uint64_t si[256];
+  double bp = -1.0;
+  uint64_t bi = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n;
+       i += (uint64_t)gridDim.x * 256) {
+    const auto a = psi[i];
+    const double p = (double)a.x * (double)a.x + (double)a.y * (double)a.y;
+    if (p > bp) {
+      bp = p;
+      bi = i;
+    }
+  }
+  sp[threadIdx.x] = bp;
+  si[threadIdx.x] = bi;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      const double op = sp[threadIdx.x + s];
+      const uint64_t oi = si[threadIdx.x + s];
+      if (op > sp[threadIdx.x] || (op == sp[threadIdx.x] && oi < si[threadIdx.x])) {
+        sp[threadIdx.x] = op;
+        si[threadIdx.x] = oi;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    best_p[blockIdx.x] = sp[0];
+    best_i[blockIdx.x] = si[0];
+  }
+}
+
+// zero every amplitude whose bit `bit` differs from `value`.
+template <typename R>
+__global__ __launch_bounds__(256) void k_project(typename AmpT<R>::type *__restrict__ psi,
+                                                  uint64_t nwork, BitIns ins) {
+  typename AmpT<R>::type z;
+  z.x = 0;
+  z.y = 0;
+  for (uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x; j < nwork;
+       j += (uint64_t)gridDim.x * 256)
+    psi[expand_index(j, ins)] = z;
+}
+
+}  // namespace qh

@@ -1,0 +1,191 @@
+"""DeviceState: a 2^n amplitude vector resident in MI355X HBM behind the C-ABI.
+
+Host-side mirror of the native half of the reference boundary: the methods
+apply1/applyc take the same arguments, in the same order and meaning, as
+State.apply1 / State.applyc (src/lib/state.py:80,102) and the libxgates entry
+points (src/lib/xgates.cc:89-145): reference (big-endian) qubit numbers and a
+2x2 (or flattened) complex gate.
+"""
+import ctypes
+
+import numpy as np
+
+from qcc_amd import gates as _gates
+from qcc_amd import native
+
+_dp = ctypes.POINTER(ctypes.c_double)
+
+
+def _g8(gate):
+  g = _gates.as8(gate)
+  return g, g.ctypes.data_as(_dp)
+
+
+class DeviceState:
+  """Owns a qh_handle.  complex128 (bit_width=128) or complex64 (64)."""
+
+  def __init__(self, nbits, bit_width=128, device=0, fusion=native.QH_FUSE_OFF, *,
+               device_ptr=None, stream=None):
+    self.lib = native.load()
+    self.nbits = int(nbits)
+    self.bit_width = int(bit_width)
+    self.dtype = np.complex128 if bit_width == 128 else np.complex64
+    h = ctypes.c_void_p()
+    if device_ptr is None:
+      native.check(self.lib.qh_create(self.nbits, self.bit_width, device, ctypes.byref(h)))
+    else:
+      native.check(self.lib.qh_attach(self.nbits, self.bit_width, device,
+                                      ctypes.c_void_p(device_ptr),
+                                      ctypes.c_void_p(stream or 0), ctypes.byref(h)))
+    self.h = h
+    self.nbits_global = self.nbits
+    if fusion != native.QH_FUSE_OFF:
+      self.set_fusion(fusion)
+
+  # -- lifetime ---------------------------------------------------------------
+  def close(self):
+    if getattr(self, 'h', None):
+      self.lib.qh_destroy(self.h)
+      self.h = None
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:  # pylint: disable=broad-except
+      pass
+
+  def __enter__(self):
+    return self
+
+  def __exit__(self, *a):
+    self.close()
+
+  # -- configuration ------------------------------------------------------------
+  def set_fusion(self, level):
+    native.check(self.lib.qh_set_fusion(self.h, int(level)))
+
+  def set_shard(self, nbits_global, shard_index):
+    native.check(self.lib.qh_set_shard(self.h, int(nbits_global), int(shard_index)))
+    self.nbits_global = int(nbits_global)
+
+  @property
+  def device_ptr(self):
+    p = ctypes.c_void_p()
+    native.check(self.lib.qh_device_ptr(self.h, ctypes.byref(p)))
+    return p.value
+
+  # -- initialisation / IO ------------------------------------------------------
+  def init_basis(self, index=0):
+    native.check(self.lib.qh_init_basis(self.h, int(index)))
+
+  def upload(self, host, offset=0):
+    a = np.ascontiguousarray(host, dtype=self.dtype)
+    native.check(self.lib.qh_upload(self.h, a.ctypes.data, int(offset), a.size))
+
+  def download(self, offset=0, count=None, out=None):
+    count = (1 << self.nbits) - offset if count is None else count
+    if out is None:
+      out = np.empty(count, dtype=self.dtype)
+    assert out.dtype == self.dtype and out.flags.c_contiguous and out.size >= count
+    native.check(self.lib.qh_download(self.h, out.ctypes.data, int(offset), int(count)))
+    return out
+
+  # -- the hot path ---------------------------------------------------------------
+  def apply1(self, gate, index):
+    _keep, p = _g8(gate)
+    native.check(self.lib.qh_apply1(self.h, int(index), p))
+
+  def applyc(self, gate, control, target):
+    _keep, p = _g8(gate)
+    native.check(self.lib.qh_applyc(self.h, int(control), int(target), p))
+
+  def apply_bits(self, ctl_mask, tgt_bit, gate):
+    _keep, p = _g8(gate)
+    native.check(self.lib.qh_apply_bits(self.h, int(ctl_mask), int(tgt_bit), p))
+
+  def run_stream(self, ops, gates8):
+    """ops int32[G,2] (ctl or NO_CTL, tgt), gates8 float64[G,8] -- reference qubit numbers."""
+    ops = np.ascontiguousarray(ops, dtype=np.int32)
+    gates8 = np.ascontiguousarray(gates8, dtype=np.float64)
+    a1, ac, h = self.lib.qh_apply1, self.lib.qh_applyc, self.h
+    base = gates8.ctypes.data
+    for k in range(len(ops)):
+      gp = ctypes.cast(base + 64 * k, _dp)
+      c, t = int(ops[k, 0]), int(ops[k, 1])
+      rc = a1(h, t, gp) if c == NO_CTL else ac(h, c, t, gp)
+      if rc:
+        native.check(rc)
+
+  def flush(self):
+    native.check(self.lib.qh_flush(self.h))
+
+  def sync(self):
+    native.check(self.lib.qh_sync(self.h))
+
+  # -- readers --------------------------------------------------------------------
+  def norm2(self):
+    v = ctypes.c_double()
+    native.check(self.lib.qh_norm2(self.h, ctypes.byref(v)))
+    return v.value
+
+  def argmax(self):
+    i, p = ctypes.c_uint64(), ctypes.c_double()
+    native.check(self.lib.qh_argmax(self.h, ctypes.byref(i), ctypes.byref(p)))
+    return self.phys_to_logical(i.value), p.value
+
+  def prob_bit(self, logical_bit):
+    v = ctypes.c_double()
+    native.check(self.lib.qh_prob_bit(self.h, int(logical_bit), ctypes.byref(v)))
+    return v.value
+
+  def scale(self, z):
+    z = complex(z)
+    native.check(self.lib.qh_scale(self.h, z.real, z.imag))
+
+  def project_bit(self, logical_bit, value):
+    native.check(self.lib.qh_project_bit(self.h, int(logical_bit), int(value)))
+
+  def phys_to_logical(self, i):
+    o = ctypes.c_uint64()
+    native.check(self.lib.qh_phys_to_logical(self.h, int(i), ctypes.byref(o)))
+    return o.value
+
+  def logical_to_phys(self, i):
+    o = ctypes.c_uint64()
+    native.check(self.lib.qh_logical_to_phys(self.h, int(i), ctypes.byref(o)))
+    return o.value
+
+  def remap_swap(self, a, b):
+    native.check(self.lib.qh_remap_swap(self.h, int(a), int(b)))
+
+  def amplitude(self, logical_index):
+    """One amplitude by LOGICAL (local) index -- 16-byte D2H."""
+    p = self.logical_to_phys(logical_index) & ((1 << self.nbits) - 1)
+    return self.download(p, 1)[0]
+
+  # -- engine measurement ---------------------------------------------------------
+  def stats(self):
+    s = native.QhStats()
+    native.check(self.lib.qh_get_stats(self.h, ctypes.byref(s)))
+    return s.as_dict()
+
+  def reset_stats(self):
+    native.check(self.lib.qh_reset_stats(self.h))
+
+  def timer_begin(self):
+    native.check(self.lib.qh_timer_begin(self.h))
+
+  def timer_end(self):
+    ms = ctypes.c_float()
+    native.check(self.lib.qh_timer_end(self.h, ctypes.byref(ms)))
+    return ms.value
+
+  def plan_json(self):
+    need = ctypes.c_uint64()
+    native.check(self.lib.qh_plan_json(self.h, None, 0, ctypes.byref(need)))
+    buf = ctypes.create_string_buffer(need.value)
+    native.check(self.lib.qh_plan_json(self.h, buf, need.value, None))
+    return buf.value.decode()
+
+
+NO_CTL = -(2 ** 31)

@@ -1,0 +1,123 @@
+"""ctypes binding of include/qcc_hip.h (libqcc_hip.so) + the build recipe.
+
+This is the only place the shared library is loaded.  It fails loudly: a
+missing library raises ImportError-like RuntimeError from load(); a missing GPU
+makes qh_create return QH_ERR_NO_DEVICE, surfaced as QhError.
+"""
+import ctypes
+import os
+import subprocess
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+LIB_PATH = os.path.join(PKG, 'libqcc_hip.so')
+SOURCES = [os.path.join(PKG, 'csrc', f) for f in
+           ('engine.hip', 'kernels_gate.hip.h', 'kernels_sweep.hip.h', 'planner.h')]
+HEADER = os.path.join(ROOT, 'include', 'qcc_hip.h')
+
+QH_OK = 0
+QH_ERR_BAD_QUBIT, QH_ERR_SAME_QUBIT, QH_ERR_BAD_DTYPE, QH_ERR_HIP = 1, 2, 3, 4
+QH_ERR_ARG, QH_ERR_NOMEM, QH_ERR_NO_DEVICE, QH_ERR_NONLOCAL = 5, 6, 7, 8
+QH_FUSE_OFF, QH_FUSE_SWEEP = 0, 1
+
+_u64, _i32, _vp, _dp = ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)
+
+
+class QhStats(ctypes.Structure):
+  _fields_ = [('gates_submitted', _u64), ('kernels_launched', _u64), ('sweeps', _u64),
+              ('bytes_algorithmic', _u64), ('bytes_swept', _u64), ('gates_noop', _u64)]
+
+  def as_dict(self):
+    return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+# name -> (restype, argtypes); every symbol declared in include/qcc_hip.h
+SIGNATURES = {
+    'qh_last_error': (ctypes.c_char_p, []),
+    'qh_version': (_i32, []),
+    'qh_device_count': (_i32, [ctypes.POINTER(_i32)]),
+    'qh_create': (_i32, [_i32, _i32, _i32, ctypes.POINTER(_vp)]),
+    'qh_attach': (_i32, [_i32, _i32, _i32, _vp, _vp, ctypes.POINTER(_vp)]),
+    'qh_create_dry': (_i32, [_i32, _i32, ctypes.POINTER(_vp)]),
+    'qh_destroy': (_i32, [_vp]),
+    'qh_set_shard': (_i32, [_vp, _i32, _u64]),
+    'qh_device_ptr': (_i32, [_vp, ctypes.POINTER(_vp)]),
+    'qh_stream': (_i32, [_vp, ctypes.POINTER(_vp)]),
+    'qh_nbits': (_i32, [_vp, ctypes.POINTER(_i32), ctypes.POINTER(_i32)]),
+    'qh_init_basis': (_i32, [_vp, _u64]),
+    'qh_upload': (_i32, [_vp, _vp, _u64, _u64]),
+    'qh_download': (_i32, [_vp, _vp, _u64, _u64]),
+    'qh_apply1': (_i32, [_vp, _i32, _dp]),
+    'qh_applyc': (_i32, [_vp, _i32, _i32, _dp]),
+    'qh_apply_bits': (_i32, [_vp, _u64, _i32, _dp]),
+    'qh_set_fusion': (_i32, [_vp, _i32]),
+    'qh_flush': (_i32, [_vp]),
+    'qh_sync': (_i32, [_vp]),
+    'qh_remap_swap': (_i32, [_vp, _i32, _i32]),
+    'qh_get_bitmap': (_i32, [_vp, ctypes.POINTER(ctypes.c_int32)]),
+    'qh_phys_to_logical': (_i32, [_vp, _u64, ctypes.POINTER(_u64)]),
+    'qh_logical_to_phys': (_i32, [_vp, _u64, ctypes.POINTER(_u64)]),
+    'qh_norm2': (_i32, [_vp, _dp]),
+    'qh_argmax': (_i32, [_vp, ctypes.POINTER(_u64), _dp]),
+    'qh_prob_bit': (_i32, [_vp, _i32, _dp]),
+    'qh_scale': (_i32, [_vp, ctypes.c_double, ctypes.c_double]),
+    'qh_project_bit': (_i32, [_vp, _i32, _i32]),
+    'qh_get_stats': (_i32, [_vp, ctypes.POINTER(QhStats)]),
+    'qh_reset_stats': (_i32, [_vp]),
+    'qh_timer_begin': (_i32, [_vp]),
+    'qh_timer_end': (_i32, [_vp, ctypes.POINTER(ctypes.c_float)]),
+    'qh_plan_json': (_i32, [_vp, ctypes.c_char_p, _u64, ctypes.POINTER(_u64)]),
+    'qh_host_apply1': (_i32, [_vp, _dp, _i32, _i32, _i32]),
+    'qh_host_applyc': (_i32, [_vp, _dp, _i32, _i32, _i32, _i32]),
+}
+
+
+class QhError(RuntimeError):
+  def __init__(self, code, msg):
+    super().__init__(f'qcc_hip error {code}: {msg}')
+    self.code = code
+
+
+def build(force=False, verbose=False):
+  """Compile the HIP engine for gfx950 in-tree (qcc_amd/libqcc_hip.so)."""
+  deps = SOURCES + [HEADER]
+  if (not force and os.path.exists(LIB_PATH)
+      and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps)):
+    return LIB_PATH
+  cmd = ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC',
+         '-o', LIB_PATH, SOURCES[0]]
+  if verbose:
+    print(' '.join(cmd))
+  subprocess.check_call(cmd, cwd=ROOT)
+  return LIB_PATH
+
+
+_lib = None
+
+
+def load():
+  """Load libqcc_hip.so and bind every declared symbol.  No fallback."""
+  global _lib
+  if _lib is not None:
+    return _lib
+  if not os.path.exists(LIB_PATH):
+    raise RuntimeError(
+        f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+        '(hipcc --offload-arch=gfx950).  qcc_amd has no CPU fallback.')
+  lib = ctypes.CDLL(LIB_PATH)
+  for name, (res, args) in SIGNATURES.items():
+    fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+    fn.restype, fn.argtypes = res, args
+  _lib = lib
+  return lib
+
+
+def check(rc):
+  if rc != QH_OK:
+    raise QhError(rc, load().qh_last_error().decode(errors='replace'))
+
+
+def device_count():
+  n = _i32(0)
+  load().qh_device_count(ctypes.byref(n))
+  return n.value

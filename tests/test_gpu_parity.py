@@ -1,0 +1,266 @@
+"""GPU parity tests: the HIP path, called through the C-ABI, against the CPU
+oracle and the reference's golden vectors.
+
+Tolerance (BASELINE.json north_star): max-abs amplitude difference <= 1e-10 for
+complex128; we assert 1e-12 on the small cases (the arithmetic is the same
+28 flops per pair, differing only by FMA contraction) and 1e-10 at full size.
+complex64: 2e-6 (reference default precision).
+"""
+import ctypes
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from qcc_amd import device, gates, native, workloads
+from tests.oracle_lib import NO_CTL
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-12
+FUSIONS = [native.QH_FUSE_OFF, native.QH_FUSE_SWEEP]
+
+
+def _rand_state(rng, n, dtype=np.complex128):
+  p = rng.standard_normal(1 << n) + 1j * rng.standard_normal(1 << n)
+  return (p / np.linalg.norm(p)).astype(dtype)
+
+
+def _rand_unitary(rng):
+  m = rng.standard_normal((2, 2)) + 1j * rng.standard_normal((2, 2))
+  q, r = np.linalg.qr(m)
+  return q * (np.diag(r) / np.abs(np.diag(r)))
+
+
+def _gate_pool(rng):
+  return [gates.hadamard(), gates.pauli_x(), gates.pauli_y(), gates.pauli_z(), gates.sgate(),
+          gates.tgate(), gates.vgate(), gates.yroot(), gates.u1(0.37), gates.rz(0.9),
+          gates.rx(0.4), _rand_unitary(rng), _rand_unitary(rng)]
+
+
+@pytest.mark.parametrize('fusion', FUSIONS)
+def test_golden_single_and_controlled(golden_dir, fusion):
+  for fname in ('g3_single.npz', 'g4_ctl_n6.npz', 'g4_ctl_n9.npz'):
+    g = np.load(os.path.join(golden_dir, fname))
+    n = int(g['nbits'])
+    with device.DeviceState(n, 128, fusion=fusion) as st:
+      for name, gate, out in zip(g['names'], g['gates'], g['outs']):
+        parts = str(name).split(':')
+        st.upload(g['psi0'])
+        if len(parts) == 2:
+          st.apply1(gate, int(parts[1]))
+        else:
+          st.applyc(gate, int(parts[1]), int(parts[2]))
+        err = np.max(np.abs(st.download() - out))
+        assert err <= TOL, (fname, name, err)
+
+
+@pytest.mark.parametrize('fusion', FUSIONS)
+def test_golden_complex64(golden_dir, fusion):
+  g = np.load(os.path.join(golden_dir, 'g7_c64.npz'))
+  n = int(g['nbits'])
+  with device.DeviceState(n, 64, fusion=fusion) as st:
+    for name, gate, out in zip(g['names'], g['gates'], g['outs']):
+      parts = str(name).split(':')
+      st.upload(g['psi0'])
+      if len(parts) == 2:
+        st.apply1(gate, int(parts[1]))
+      else:
+        st.applyc(gate, int(parts[1]), int(parts[2]))
+      got = st.download()
+      assert got.dtype == np.complex64
+      assert np.max(np.abs(got - out)) <= 2e-6, name
+
+
+@pytest.mark.parametrize('fusion', FUSIONS)
+def test_golden_traces(golden_dir, fusion):
+  """Recorded native call streams of reference circuits (QFT, supremacy, Grover,
+  multi_control, the negative-control sequence of circuit_test.py:97-102)."""
+  files = sorted(glob.glob(os.path.join(golden_dir, 'g5_*.npz'))) + [
+      os.path.join(golden_dir, 'g1_qft12.npz'), os.path.join(golden_dir, 'py_fallback.npz')]
+  assert len(files) >= 10
+  for f in files:
+    g = np.load(f)
+    n = int(g['nbits'])
+    with device.DeviceState(n, 128, fusion=fusion) as st:
+      st.upload(g['init'])
+      st.run_stream(g['ops'], g['gates'])
+      got = st.download()
+    err = np.max(np.abs(got - g['final']))
+    assert err <= 1e-10, (os.path.basename(f), err)
+    assert err <= 2e-13, (os.path.basename(f), err)
+
+
+@pytest.mark.parametrize('fusion', FUSIONS)
+@pytest.mark.parametrize('n', [1, 2, 3, 5, 6, 7, 10, 11, 12, 13, 16])
+def test_every_target_and_control_vs_oracle(oracle, fusion, n):
+  rng = np.random.default_rng(100 + n)
+  psi0 = _rand_state(rng, n)
+  pool = _gate_pool(rng)
+  with device.DeviceState(n, 128, fusion=fusion) as st:
+    for t in range(n):
+      for gi in rng.choice(len(pool), size=3, replace=False):
+        want = psi0.copy()
+        oracle.apply1(want, pool[gi], n, t)
+        st.upload(psi0)
+        st.apply1(pool[gi], t)
+        assert np.max(np.abs(st.download() - want)) <= TOL, (n, t, gi)
+    pairs = [(c, t) for c in range(n) for t in range(n) if c != t]
+    if len(pairs) > 40:
+      pairs = [pairs[i] for i in rng.choice(len(pairs), size=40, replace=False)]
+    for c, t in pairs:
+      gi = int(rng.integers(len(pool)))
+      want = psi0.copy()
+      oracle.applyc(want, pool[gi], n, c, t)
+      st.upload(psi0)
+      st.applyc(pool[gi], c, t)
+      assert np.max(np.abs(st.download() - want)) <= TOL, (n, c, t, gi)
+
+
+@pytest.mark.parametrize('fusion', FUSIONS)
+@pytest.mark.parametrize('n,ngates,seed', [(4, 60, 0), (9, 150, 1), (12, 300, 2), (15, 400, 3), (20, 250, 4)])
+def test_random_streams_vs_oracle(oracle, fusion, n, ngates, seed):
+  rng = np.random.default_rng(seed)
+  pool = _gate_pool(rng)
+  ops, gs = [], []
+  for _ in range(ngates):
+    t = int(rng.integers(n))
+    g = pool[int(rng.integers(len(pool)))]
+    if n > 1 and rng.random() < 0.55:
+      c = int((t + 1 + rng.integers(n - 1)) % n)
+      ops.append((c, t))
+    else:
+      ops.append((NO_CTL, t))
+    gs.append(np.asarray(g, dtype=np.complex128).reshape(4))
+  ops = np.array(ops, dtype=np.int32)
+  g8 = np.array(gs).view(np.float64).reshape(-1, 8)
+  psi0 = _rand_state(rng, n)
+  want = psi0.copy()
+  oracle.run_stream(want, n, ops, g8)
+  with device.DeviceState(n, 128, fusion=fusion) as st:
+    st.upload(psi0)
+    st.run_stream(ops, g8)
+    got = st.download()
+    n2 = st.norm2()
+  assert np.max(np.abs(got - want)) <= 1e-11
+  assert abs(n2 - 1.0) < 1e-11
+
+
+def test_multi_control_masks_vs_oracle(oracle):
+  """qh_apply_bits with several control bits == nested reference semantics."""
+  n = 10
+  rng = np.random.default_rng(9)
+  psi0 = _rand_state(rng, n)
+  u = _rand_unitary(rng)
+  for fusion in FUSIONS:
+    with device.DeviceState(n, 128, fusion=fusion) as st:
+      for mask, tbit in ((0b0000000110, 0), (0b1000000001, 5), (0b0101010000, 9), (0b0000111000, 2)):
+        want = psi0.copy()
+        idx = np.arange(1 << n)
+        sel = ((idx & mask) == mask) & (((idx >> tbit) & 1) == 0)
+        a, b = want[idx[sel]], want[idx[sel] | (1 << tbit)]
+        want[idx[sel]] = u[0, 0] * a + u[0, 1] * b
+        want[idx[sel] | (1 << tbit)] = u[1, 0] * a + u[1, 1] * b
+        st.upload(psi0)
+        st.apply_bits(mask, tbit, u)
+        assert np.max(np.abs(st.download() - want)) <= TOL
+
+
+def test_host_dropin_entry_points(oracle):
+  lib = native.load()
+  dp = ctypes.POINTER(ctypes.c_double)
+  rng = np.random.default_rng(1)
+  for bw, dtype, tol in ((128, np.complex128, TOL), (64, np.complex64, 2e-6)):
+    n = 9
+    psi = _rand_state(rng, n, dtype)
+    want = psi.copy()
+    g = _rand_unitary(rng)
+    g8 = gates.as8(g)
+    native.check(lib.qh_host_apply1(psi.ctypes.data, g8.ctypes.data_as(dp), n, 3, bw))
+    oracle.apply1(want, g, n, 3)
+    native.check(lib.qh_host_applyc(psi.ctypes.data, g8.ctypes.data_as(dp), n, 8, 0, bw))
+    oracle.applyc(want, g, n, 8, 0)
+    native.check(lib.qh_host_applyc(psi.ctypes.data, g8.ctypes.data_as(dp), n, -2, 5, bw))
+    oracle.applyc(want, g, n, -2, 5)
+    assert np.max(np.abs(psi - want)) <= tol
+
+
+def test_readers(oracle):
+  n = 14
+  rng = np.random.default_rng(4)
+  psi = _rand_state(rng, n)
+  with device.DeviceState(n, 128) as st:
+    st.upload(psi)
+    assert abs(st.norm2() - 1.0) < 1e-12
+    idx, p = st.argmax()
+    assert idx == int(np.argmax(np.abs(psi))) and abs(p - np.abs(psi[idx]) ** 2) < 1e-15
+    for bit in (0, 5, 13):
+      want = float(np.sum(np.abs(psi[((np.arange(1 << n) >> bit) & 1) == 1]) ** 2))
+      assert abs(st.prob_bit(bit) - want) < 1e-12
+    st.project_bit(5, 1)
+    proj = psi.copy()
+    proj[((np.arange(1 << n) >> 5) & 1) == 0] = 0
+    assert np.max(np.abs(st.download() - proj)) == 0
+    st.scale(2.0 - 1.0j)
+    assert np.max(np.abs(st.download() - proj * (2.0 - 1.0j))) < 1e-15
+    st.init_basis(77)
+    got = st.download()
+    assert got[77] == 1 and np.count_nonzero(got) == 1
+
+
+def test_qft22_sampled_golden(golden_dir):
+  g = np.load(os.path.join(golden_dir, 'g6_qft22.npz'))
+  n, x = int(g['nbits']), int(g['x'])
+  ops, g8 = workloads.qft_stream(range(n)).arrays()
+  for fusion in FUSIONS:
+    with device.DeviceState(n, 128, fusion=fusion) as st:
+      st.init_basis(x)
+      st.run_stream(ops, g8)
+      got = st.download()
+    assert np.max(np.abs(got[g['idx']] - g['amp'])) <= 1e-12
+    assert abs(np.vdot(got, got).real - 1) < 1e-12
+
+
+@pytest.mark.parametrize('fusion', FUSIONS)
+def test_full_size_30q_properties(fusion):
+  """BASELINE config 2 size: 30-qubit QFT.  The reference cannot be run at this
+  size in seconds, so: closed form on sampled indices, norm, and QFT followed by
+  the inverse circuit returns the basis state (size-independent properties)."""
+  n = 30
+  x = 0x2CB9A5E3 & ((1 << n) - 1)
+  ops, g8 = workloads.qft_stream(range(n)).arrays()
+  with device.DeviceState(n, 128, fusion=fusion) as st:
+    st.init_basis(x)
+    st.run_stream(ops, g8)
+    assert abs(st.norm2() - 1.0) < 1e-10
+    rng = np.random.default_rng(30)
+    idx = rng.integers(0, 1 << n, size=512)
+    want = workloads.qft_analytic(n, x, idx)
+    got = np.array([st.amplitude(int(i)) for i in idx])
+    assert np.max(np.abs(got - want)) <= 1e-10
+    # a contiguous window too (exercises low bits)
+    win = st.download(offset=(1 << 29) + 12345, count=4096)
+    wantw = workloads.qft_analytic(n, x, np.arange((1 << 29) + 12345, (1 << 29) + 12345 + 4096))
+    assert np.max(np.abs(win - wantw)) <= 1e-10
+    # inverse: adjoint gates in reverse order
+    inv_ops = ops[::-1].copy()
+    inv_g = g8[::-1].copy().reshape(-1, 4, 2)
+    inv_c = inv_g[..., 0] + 1j * inv_g[..., 1]
+    inv_c = np.conj(inv_c.reshape(-1, 2, 2).transpose(0, 2, 1)).reshape(-1, 4)
+    st.run_stream(inv_ops, np.ascontiguousarray(inv_c).view(np.float64).reshape(-1, 8))
+    i, p = st.argmax()
+    assert i == x and abs(p - 1.0) < 1e-10
+    assert abs(st.norm2() - 1.0) < 1e-10
+
+
+def test_error_behaviour_on_device():
+  with device.DeviceState(6, 128) as st:
+    with pytest.raises(native.QhError) as e:
+      st.apply1(gates.hadamard(), 6)
+    assert e.value.code == native.QH_ERR_BAD_QUBIT
+    with pytest.raises(native.QhError) as e:
+      st.applyc(gates.hadamard(), 2, 2)
+    assert e.value.code == native.QH_ERR_SAME_QUBIT
+    st.init_basis(0)
+    st.apply1(gates.hadamard(), 0)  # still usable after errors
+    assert abs(st.norm2() - 1) < 1e-15
