@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -215,7 +216,7 @@ int check_launch(qh_state_s *h) {
 int flush_impl(qh_state_s *h) {
   if (h->queue.empty()) return QH_OK;
   int rc = QH_OK;
-  if (h->fusion == QH_FUSE_SWEEP && qh::sweep_supported(h->nloc)) {
+  if (h->fusion == QH_FUSE_SWEEP && qh::sweep_supported(h->nloc, h->bw)) {
     rc = qh::run_fused(h->queue, h->nloc, h->shard, h->bw, h->d_psi, h->stream, h->dry,
                        &h->sweep, &h->stats, &g_err);
     if (rc == QH_OK) rc = check_launch(h);

@@ -12,7 +12,9 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 LIB_PATH = os.path.join(PKG, 'libqcc_hip.so')
 SOURCES = [os.path.join(PKG, 'csrc', f) for f in
-           ('engine.hip', 'kernels_gate.hip.h', 'kernels_sweep.hip.h', 'planner.h')]
+           ('engine.hip', 'kernels_gate.hip.h', 'kernels_sweep.hip.h', 'planner.h',
+            'sweep_island_rb2.inc', 'sweep_island_rb3.inc', 'sweep_island_rb4.inc',
+            'sweep_island_rb5.inc')]
 HEADER = os.path.join(ROOT, 'include', 'qcc_hip.h')
 
 QH_OK = 0

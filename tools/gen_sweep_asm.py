@@ -1,0 +1,334 @@
+#!/usr/bin/env python3
+"""Generates qcc_amd/csrc/sweep_island_rb{2..5}.inc: the per-tile body of the
+fused sweep kernel (kernels_sweep.hip.h) as gfx950 assembly with FIXED physical
+registers.
+
+Why assembly: the tile (2^RB complex128 amplitudes per lane = up to 128 VGPRs)
+must stay in the same registers across an interpreter loop over queued gate ops.
+hipcc's register allocator copies the whole tile at every op-kind branch (2x the
+VGPRs, spills at RB=5, one v_mov per amplitude per op), so the loop is written
+by hand: every op updates the tile in place.
+
+Register map (island-private, declared as clobbers to the compiler):
+  v[64+4k .. 64+4k+3]   tile slot k: x = v[+0:+1], y = v[+2:+3]
+  v16..v63              temporaries (see names below)
+  s36..s99              scalar state (op header, gate matrix, cursors, masks)
+Operands supplied by the C++ kernel:
+  %0,%1  tile base address lo,hi (SGPR)      %2  SweepParams* (SGPR pair)
+  %3     tile index (idx_high|base) (SGPR pair, for outside-bit predicates)
+  %4     lane*16 (VGPR)  %5 lane (VGPR)  %6,%7 thread index lo,hi (VGPR)
+Data layouts must match planner.h (SweepOp 96 B, DGroup 32 B, OTerm 24 B) and
+kernels_sweep.hip.h (SweepParams: slot byte offsets at +0x40).
+"""
+import os
+import sys
+
+OP_DENSE_REG, OP_DENSE_LANE, OP_DIAG = 0, 1, 2
+
+
+def T(k):
+  return 64 + 4 * k
+
+
+def X(k):
+  return f'v[{T(k)}:{T(k) + 1}]'
+
+
+def Y(k):
+  return f'v[{T(k) + 2}:{T(k) + 3}]'
+
+
+class Asm:
+  def __init__(self):
+    self.lines = []
+
+  def __call__(self, s):
+    self.lines.append(s)
+
+  def label(self, name):
+    self.lines.append(f'{name}_%=:')
+
+
+def L(name):
+  return f'{name}_%='
+
+
+def cmul_pair(a, slots, fr, fi):
+  """slot *= (fr,fi) for 1 or 2 slots, interleaved; temps v[28:29], v[30:31]."""
+  tmps = ['v[28:29]', 'v[30:31]']
+  for t, k in zip(tmps, slots):
+    a(f'v_mul_f64 {t}, {X(k)}, {fr}')
+  for t, k in zip(tmps, slots):
+    a(f'v_fma_f64 {t}, -{Y(k)}, {fi}, {t}')
+  for t, k in zip(tmps, slots):
+    a(f'v_mul_f64 {Y(k)}, {Y(k)}, {fr}')
+  for t, k in zip(tmps, slots):
+    a(f'v_fma_f64 {Y(k)}, {X(k)}, {fi}, {Y(k)}')
+  for t, k in zip(tmps, slots):
+    a(f'v_mov_b64 {X(k)}, {t}')
+
+
+def gen(rb):
+  nr = 1 << rb
+  a = Asm()
+  batch = min(8, nr)
+  # ---- prologue: parameters -------------------------------------------------
+  a('s_load_dwordx4 s[36:39], %2, 0x0')   # ops cursor, groups base
+  a('s_load_dwordx2 s[40:41], %2, 0x10')  # oterms base
+  a('s_load_dword s42, %2, 0x18')         # nops
+  # ---- load the tile: one 1-KiB global_load_dwordx4 per slot ----------------
+  for j in range(nr // batch):
+    a(f's_load_dwordx{2 * batch} s[52:{52 + 2 * batch - 1}], %2, {0x40 + 8 * batch * j}')
+    a('s_waitcnt lgkmcnt(0)')
+    for i in range(batch):
+      k = batch * j + i
+      a(f's_add_u32 s98, %0, s{52 + 2 * i}')
+      a(f's_addc_u32 s99, %1, s{53 + 2 * i}')
+      a(f'global_load_dwordx4 v[{T(k)}:{T(k) + 3}], %4, s[98:99]')
+  a('s_mov_b32 s43, 0')
+  a('s_waitcnt vmcnt(0)')
+  # ---- op loop ------------------------------------------------------------------
+  a.label('L_op')
+  a('s_cmp_ge_u32 s43, s42')
+  a(f's_cbranch_scc1 {L("L_done")}')
+  a('s_load_dwordx8 s[44:51], s[36:37], 0x0')    # kind tb cm_reg n_groups cm_thread(2) group_off pad
+  a('s_load_dwordx16 s[52:67], s[36:37], 0x20')  # g[8]
+  a('s_waitcnt lgkmcnt(0)')
+  a('s_cmp_eq_u32 s44, 2')
+  a(f's_cbranch_scc1 {L("L_diag")}')
+  # control predicate of this thread: (it & cm_thread) == cm_thread  -> s[68:69]
+  a('v_and_b32 v16, s48, %6')
+  a('v_and_b32 v17, s49, %7')
+  a('v_cmp_eq_u32 vcc, s48, v16')
+  a('v_cmp_eq_u32_e64 s[72:73], s49, v17')
+  a('s_nop 1')
+  a('s_and_b64 s[68:69], vcc, s[72:73]')
+  a('s_cmp_eq_u32 s44, 1')
+  a(f's_cbranch_scc1 {L("L_lane")}')
+  for b in range(rb):
+    a(f's_cmp_eq_u32 s45, {b}')
+    a(f's_cbranch_scc1 {L(f"L_reg{b}")}')
+  a.label('L_next')
+  a('s_add_u32 s36, s36, 96')
+  a('s_addc_u32 s37, s37, 0')
+  a('s_add_u32 s43, s43, 1')
+  a(f's_branch {L("L_op")}')
+
+  # ---- dense 2x2 on register bit b: in-place butterflies --------------------------
+  g = {'g0r': 's[52:53]', 'g0i': 's[54:55]', 'g1r': 's[56:57]', 'g1i': 's[58:59]',
+       'g2r': 's[60:61]', 'g2i': 's[62:63]', 'g3r': 's[64:65]', 'g3i': 's[66:67]'}
+  for b in range(rb):
+    a.label(f'L_reg{b}')
+    for h in range(nr // 2):
+      k0 = ((h >> b) << (b + 1)) | (h & ((1 << b) - 1))
+      k1 = k0 | (1 << b)
+      skip = f'L_r{b}_{h}'
+      a(f's_andn2_b32 s74, s46, {k0}')      # control bits (register part) not set in k0
+      a('s_cmp_eq_u32 s74, 0')
+      a(f's_cbranch_scc0 {L(skip)}')
+      ar, ai, br, bi = X(k0), Y(k0), X(k1), Y(k1)
+      t0, t1, t2, t3 = 'v[32:33]', 'v[34:35]', 'v[36:37]', 'v[38:39]'
+      a(f'v_mul_f64 {t0}, {g["g0r"]}, {ar}')
+      a(f'v_mul_f64 {t1}, {g["g0r"]}, {ai}')
+      a(f'v_mul_f64 {t2}, {g["g2r"]}, {ar}')
+      a(f'v_mul_f64 {t3}, {g["g2r"]}, {ai}')
+      a(f'v_fma_f64 {t0}, -{g["g0i"]}, {ai}, {t0}')
+      a(f'v_fma_f64 {t1}, {g["g0i"]}, {ar}, {t1}')
+      a(f'v_fma_f64 {t2}, -{g["g2i"]}, {ai}, {t2}')
+      a(f'v_fma_f64 {t3}, {g["g2i"]}, {ar}, {t3}')
+      a(f'v_fma_f64 {t0}, {g["g1r"]}, {br}, {t0}')
+      a(f'v_fma_f64 {t1}, {g["g1r"]}, {bi}, {t1}')
+      a(f'v_fma_f64 {t2}, {g["g3r"]}, {br}, {t2}')
+      a(f'v_fma_f64 {t3}, {g["g3r"]}, {bi}, {t3}')
+      a(f'v_fma_f64 {t0}, -{g["g1i"]}, {bi}, {t0}')
+      a(f'v_fma_f64 {t1}, {g["g1i"]}, {br}, {t1}')
+      a(f'v_fma_f64 {t2}, -{g["g3i"]}, {bi}, {t2}')
+      a(f'v_fma_f64 {t3}, {g["g3i"]}, {br}, {t3}')
+      a('s_and_saveexec_b64 s[70:71], s[68:69]')
+      a(f'v_mov_b64 {ar}, {t0}')
+      a(f'v_mov_b64 {ai}, {t1}')
+      a(f'v_mov_b64 {br}, {t2}')
+      a(f'v_mov_b64 {bi}, {t3}')
+      a('s_mov_b64 exec, s[70:71]')
+      a.label(skip)
+    a(f's_branch {L("L_next")}')
+
+  # ---- dense 2x2 on a lane bit: partner via ds_bpermute ------------------------------
+  a.label('L_lane')
+  a('s_lshl_b32 s74, 1, s45')           # m = 1 << tb
+  a('v_xor_b32 v48, s74, %5')
+  a('v_lshlrev_b32 v48, 2, v48')        # bpermute byte address of the partner lane
+  a('v_and_b32 v49, s74, %5')
+  a('v_cmp_ne_u32 vcc, 0, v49')         # this lane holds the "1" element of the pair
+  # new = ca*mine + cb*other ; ca = hi ? g3 : g0 ; cb = hi ? g2 : g1
+  coef = {'car': 50, 'cai': 52, 'cbr': 54, 'cbi': 56}
+  src = {'car': (52, 64), 'cai': (54, 66), 'cbr': (56, 60), 'cbi': (58, 62)}
+  for name, v in coef.items():
+    lo, hi = src[name]
+    for d in range(2):
+      a(f'v_mov_b32 v{v + d}, s{lo + d}')
+      a(f'v_mov_b32 v49, s{hi + d}')
+      a(f'v_cndmask_b32 v{v + d}, v{v + d}, v49, vcc')
+  car, cai, cbr, cbi = 'v[50:51]', 'v[52:53]', 'v[54:55]', 'v[56:57]'
+
+  def shuf(k, buf):
+    for d in range(4):
+      a(f'ds_bpermute_b32 v{buf + d}, v48, v{T(k) + d}')
+
+  def combine(k, buf):
+    orr, oi = f'v[{buf}:{buf + 1}]', f'v[{buf + 2}:{buf + 3}]'
+    t0, t1 = 'v[32:33]', 'v[34:35]'
+    a(f'v_mul_f64 {t0}, {car}, {X(k)}')
+    a(f'v_mul_f64 {t1}, {car}, {Y(k)}')
+    a(f'v_fma_f64 {t0}, -{cai}, {Y(k)}, {t0}')
+    a(f'v_fma_f64 {t1}, {cai}, {X(k)}, {t1}')
+    a(f'v_fma_f64 {t0}, {cbr}, {orr}, {t0}')
+    a(f'v_fma_f64 {t1}, {cbr}, {oi}, {t1}')
+    a(f'v_fma_f64 {t0}, -{cbi}, {oi}, {t0}')
+    a(f'v_fma_f64 {t1}, {cbi}, {orr}, {t1}')
+    a('s_and_saveexec_b64 s[70:71], s[68:69]')
+    a(f'v_mov_b64 {X(k)}, {t0}')
+    a(f'v_mov_b64 {Y(k)}, {t1}')
+    a('s_mov_b64 exec, s[70:71]')
+
+  a('s_cmp_eq_u32 s46, 0')
+  a(f's_cbranch_scc0 {L("L_lane_ctl")}')
+  # fast path (no register-bit controls): shuffles of slot k+1 in flight while slot k combines
+  bufs = [40, 44]
+  shuf(0, bufs[0])
+  for k in range(nr):
+    if k + 1 < nr:
+      shuf(k + 1, bufs[(k + 1) & 1])
+      a('s_waitcnt lgkmcnt(4)')
+    else:
+      a('s_waitcnt lgkmcnt(0)')
+    combine(k, bufs[k & 1])
+  a(f's_branch {L("L_next")}')
+  a.label('L_lane_ctl')
+  for k in range(nr):
+    skip = f'L_l_{k}'
+    a(f's_andn2_b32 s74, s46, {k}')
+    a('s_cmp_eq_u32 s74, 0')
+    a(f's_cbranch_scc0 {L(skip)}')
+    shuf(k, 40)
+    a('s_waitcnt lgkmcnt(0)')
+    combine(k, 40)
+    a.label(skip)
+  a(f's_branch {L("L_next")}')
+
+  # ---- diagonal op: groups of phase factors -------------------------------------------
+  a.label('L_diag')
+  a('v_mov_b32 v20, 0')
+  a('v_mov_b32 v21, 0x3ff00000')   # c = 1.0 + 0.0i  (cr = v[20:21], ci = v[22:23])
+  a('v_mov_b32 v22, 0')
+  a('v_mov_b32 v23, 0')
+  a('s_mov_b32 s75, 0')            # c modified?
+  a('s_cmp_eq_u32 s47, 0')
+  a(f's_cbranch_scc1 {L("L_next")}')
+  a('s_lshl_b32 s74, s50, 5')      # group_off * sizeof(DGroup)=32
+  a('s_add_u32 s92, s38, s74')
+  a('s_addc_u32 s93, s39, 0')
+  a('s_mov_b32 s96, 0')
+  a.label('L_grp')
+  a('s_load_dwordx8 s[76:83], s[92:93], 0x0')  # lane_mask reg_mask oterm_off n_oterms re(2) im(2)
+  a('s_waitcnt lgkmcnt(0)')
+  a('v_mov_b32 v24, s80')
+  a('v_mov_b32 v25, s81')          # u = v[24:25] + i v[26:27]  (wave-uniform value)
+  a('v_mov_b32 v26, s82')
+  a('v_mov_b32 v27, s83')
+  a('s_cmp_eq_u32 s79, 0')
+  a(f's_cbranch_scc1 {L("L_grp_f")}')
+  a('s_mul_i32 s74, s78, 24')      # oterm_off * sizeof(OTerm)=24
+  a('s_add_u32 s94, s40, s74')
+  a('s_addc_u32 s95, s41, 0')
+  a('s_mov_b32 s97, 0')
+  a.label('L_ot')
+  a('s_load_dwordx2 s[84:85], s[94:95], 0x0')
+  a('s_load_dwordx4 s[88:91], s[94:95], 0x8')
+  a('s_waitcnt lgkmcnt(0)')
+  a('s_and_b64 s[86:87], %3, s[84:85]')
+  a('s_cmp_eq_u64 s[86:87], s[84:85]')
+  a(f's_cbranch_scc0 {L("L_ot_n")}')
+  a('v_mul_f64 v[28:29], v[24:25], s[88:89]')
+  a('v_fma_f64 v[28:29], -v[26:27], s[90:91], v[28:29]')
+  a('v_mul_f64 v[26:27], v[26:27], s[88:89]')
+  a('v_fma_f64 v[26:27], v[24:25], s[90:91], v[26:27]')
+  a('v_mov_b64 v[24:25], v[28:29]')
+  a.label('L_ot_n')
+  a('s_add_u32 s94, s94, 24')
+  a('s_addc_u32 s95, s95, 0')
+  a('s_add_u32 s97, s97, 1')
+  a('s_cmp_lt_u32 s97, s79')
+  a(f's_cbranch_scc1 {L("L_ot")}')
+  a.label('L_grp_f')
+  # f = lane_ok ? u : 1   (fr = v[58:59], fi = v[60:61])
+  a('v_and_b32 v16, s76, %5')
+  a('v_cmp_eq_u32 vcc, s76, v16')
+  a('v_mov_b32 v17, 0x3ff00000')
+  a('v_cndmask_b32 v58, 0, v24, vcc')
+  a('v_cndmask_b32 v59, v17, v25, vcc')
+  a('v_cndmask_b32 v60, 0, v26, vcc')
+  a('v_cndmask_b32 v61, 0, v27, vcc')
+  a('s_cmp_eq_u32 s77, 0')
+  a(f's_cbranch_scc0 {L("L_grp_r")}')
+  # c *= f
+  a('v_mul_f64 v[28:29], v[20:21], v[58:59]')
+  a('v_fma_f64 v[28:29], -v[22:23], v[60:61], v[28:29]')
+  a('v_mul_f64 v[22:23], v[22:23], v[58:59]')
+  a('v_fma_f64 v[22:23], v[20:21], v[60:61], v[22:23]')
+  a('v_mov_b64 v[20:21], v[28:29]')
+  a('s_mov_b32 s75, 1')
+  a(f's_branch {L("L_grp_n")}')
+  a.label('L_grp_r')
+  for k in range(nr):
+    skip = f'L_g_{k}'
+    a(f's_andn2_b32 s74, s77, {k}')
+    a('s_cmp_eq_u32 s74, 0')
+    a(f's_cbranch_scc0 {L(skip)}')
+    cmul_pair(a, [k], 'v[58:59]', 'v[60:61]')
+    a.label(skip)
+  a.label('L_grp_n')
+  a('s_add_u32 s92, s92, 32')
+  a('s_addc_u32 s93, s93, 0')
+  a('s_add_u32 s96, s96, 1')
+  a('s_cmp_lt_u32 s96, s47')
+  a(f's_cbranch_scc1 {L("L_grp")}')
+  a('s_cmp_eq_u32 s75, 0')
+  a(f's_cbranch_scc1 {L("L_next")}')
+  for k in range(0, nr, 2):
+    cmul_pair(a, [k, k + 1], 'v[20:21]', 'v[22:23]')
+  a(f's_branch {L("L_next")}')
+
+  # ---- store the tile ----------------------------------------------------------------------
+  a.label('L_done')
+  for j in range(nr // batch):
+    a(f's_load_dwordx{2 * batch} s[52:{52 + 2 * batch - 1}], %2, {0x40 + 8 * batch * j}')
+    a('s_waitcnt lgkmcnt(0)')
+    for i in range(batch):
+      k = batch * j + i
+      a(f's_add_u32 s98, %0, s{52 + 2 * i}')
+      a(f's_addc_u32 s99, %1, s{53 + 2 * i}')
+      a(f'global_store_dwordx4 %4, v[{T(k)}:{T(k) + 3}], s[98:99]')
+  a('s_nop 0')
+
+  clob = [f'v{i}' for i in range(16, 64 + 4 * nr)] + [f's{i}' for i in range(36, 100)] + ['vcc', 'scc', 'memory']
+  body = '\n'.join(f'    "{ln}\\n\\t"' for ln in a.lines)
+  cl = ', '.join(f'"{c}"' for c in clob)
+  return (f'// GENERATED by tools/gen_sweep_asm.py (RB={rb}) -- do not edit.\n'
+          f'asm volatile(\n{body}\n'
+          '    :\n'
+          '    : "s"(base_lo), "s"(base_hi), "s"(prm), "s"(tile_idx), "v"(voff), "v"(lane_u), "v"(it_lo), "v"(it_hi)\n'
+          f'    : {cl});\n')
+
+
+def main():
+  out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'qcc_amd', 'csrc')
+  for rb in (2, 3, 4, 5):
+    path = os.path.join(out, f'sweep_island_rb{rb}.inc')
+    with open(path, 'w') as f:
+      f.write(gen(rb))
+    print('wrote', path, sum(1 for _ in open(path)), 'lines')
+
+
+if __name__ == '__main__':
+  sys.exit(main())
