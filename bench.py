@@ -142,6 +142,7 @@ def main():
   eng.init_basis(x)
   for _ in range(args.warmup):
     eng.run_stream(ops, g8)
+    eng.flush()  # a step is one observable qc.qft(): never fuse across steps
   eng.sync()
   eng.reset_stats()
   if dist is not None:
@@ -150,6 +151,7 @@ def main():
   eng.timer_begin()
   for _ in range(args.steps):
     eng.run_stream(ops, g8)
+    eng.flush()
   ev_ms = eng.timer_end()  # flushes + waits for the stream
   eng.sync()
   if dist is not None:

@@ -56,12 +56,21 @@ struct OTerm {
   uint64_t mask;
   double re, im;
 };
-// A diagonal group: f = phi0 * prod(oterms that apply); applied to lanes with
-// (lane & lane_mask) == lane_mask and register slots with (k & reg_mask) == reg_mask.
+// A diagonal group.  Wave-uniform part u = phi0 * prod(chunk-table lookups) *
+// prod(oterms that apply).  Per-lane factor f = ltab[lane] * u when LTAB is set,
+// else ((lane & lane_mask) == lane_mask ? u : 1).  f multiplies the register
+// slots k with (k & reg_mask) == reg_mask.
+//   chunk table t: 256 entries indexed by (tile_idx >> shift_t) & 255 -- the
+//   product of the single-bit outside factors of 8 consecutive index bits;
+//   lane table: 64 entries, product of all merged pure-lane factors.
+constexpr uint32_t DG_LTAB = 1u;
 struct DGroup {
   uint32_t lane_mask, reg_mask;
   uint32_t oterm_off, n_oterms;
   double re, im;
+  uint32_t flags, ltab_off;   // ltab_off/tab_off: in 16-byte entries of SweepPlan::tables
+  uint32_t ntab, tab_shift;   // tab_shift: 4 x u8
+  uint32_t tab_off[4];
 };
 struct SweepOp {
   uint32_t kind;       // OP_*
@@ -82,6 +91,7 @@ struct SweepPlan {
   std::vector<SweepOp> ops;
   std::vector<DGroup> groups;
   std::vector<OTerm> oterms;
+  std::vector<double> tables;      // (re,im) pairs: lane tables and chunk tables
   // accounting
   uint64_t gates = 0;              // reference gate applications executed by this sweep
   uint64_t alg_bytes = 0;          // their minimal-touch bytes
@@ -252,28 +262,26 @@ class Planner {
     }
   }
 
-  struct OpenDiag {  // a DIAG op still accepting gates
-    int op_index = -1;
-  };
+  struct PTerm { uint64_t mask; double re, im; };
 
+  // Diagonal gates are placed LAZILY: a phase term stays pending until a dense
+  // op targets one of its bits (or the sweep ends), so the terms of many
+  // reference gates meet in few DIAG ops and merge into tables.
   void emit_ops(const std::vector<const GateRec *> &taken, SweepPlan *sp) {
-    // per bit: index of the last op acting densely on it (-1 none)
-    int last_dense[64];
-    for (int &v : last_dense) v = -1;
-    int open_diag = -1;  // index in sp->ops of the most recent DIAG op
-    // groups of the open diag op are collected here and flushed at the end
-    struct PGroup { uint32_t lane, reg; double re, im; std::vector<OTerm> ot; };
-    std::vector<std::vector<PGroup>> diag_groups;  // per DIAG op
-    std::vector<int> diag_op_ids;
-    auto diag_slot = [&](int op_id) -> std::vector<PGroup> & {
-      for (size_t k = 0; k < diag_op_ids.size(); ++k) if (diag_op_ids[k] == op_id) return diag_groups[k];
-      diag_op_ids.push_back(op_id);
-      diag_groups.emplace_back();
-      return diag_groups.back();
+    std::vector<PTerm> pending;
+    auto add_pending = [&](uint64_t mask, double re, double im) {
+      if (is_one(re, im)) return;
+      for (auto &t : pending) if (t.mask == mask) {
+        const double nr = t.re * re - t.im * im, ni = t.re * im + t.im * re;
+        t.re = nr; t.im = ni;
+        return;
+      }
+      pending.push_back(PTerm{mask, re, im});
     };
     for (const GateRec *r : taken) {
       const bool diag = plan_diag(r->g, r->tgt);
       if (!diag) {
+        flush_diag(&pending, 1ull << r->tgt, sp);
         SweepOp op{};
         uint32_t lane, reg; uint64_t outside;
         split_mask(*sp, r->ctl_mask, &lane, &reg, &outside);
@@ -282,66 +290,116 @@ class Planner {
         memcpy(op.g, r->g, sizeof op.g);
         if (r->tgt < kLaneBits) { op.kind = OP_DENSE_LANE; op.tb = r->tgt; }
         else { op.kind = OP_DENSE_REG; op.tb = reg_index(*sp, r->tgt); }
-        last_dense[r->tgt] = (int)sp->ops.size();
         sp->ops.push_back(op);
         continue;
       }
       // diagonal: amp *= d0 under controls (if d0 != 1), then amp *= d1/d0 where tgt set
-      uint64_t bits = r->ctl_mask | (r->tgt >= 0 ? (1ull << r->tgt) : 0);
-      int newest_dense = -1;
-      for (uint64_t t = bits; t; t &= t - 1) newest_dense = std::max(newest_dense, last_dense[__builtin_ctzll(t)]);
-      if (open_diag < 0 || open_diag < newest_dense) {
-        SweepOp op{};
-        op.kind = OP_DIAG;
-        open_diag = (int)sp->ops.size();
-        sp->ops.push_back(op);
-      }
-      auto &groups = diag_slot(open_diag);
-      auto add_term = [&](uint64_t mask, double re, double im) {
-        if (is_one(re, im)) return;
-        uint32_t lane, reg; uint64_t outside;
-        split_mask(*sp, mask, &lane, &reg, &outside);
-        PGroup *g = nullptr;
-        for (auto &pg : groups) if (pg.lane == lane && pg.reg == reg) { g = &pg; break; }
-        if (!g) { groups.push_back(PGroup{lane, reg, 1.0, 0.0, {}}); g = &groups.back(); }
-        if (outside == 0) {
-          const double nr = g->re * re - g->im * im, ni = g->re * im + g->im * re;
-          g->re = nr; g->im = ni;
-        } else {
-          for (auto &t : g->ot) if (t.mask == outside) {
-            const double nr = t.re * re - t.im * im, ni = t.re * im + t.im * re;
-            t.re = nr; t.im = ni;
-            return;
-          }
-          g->ot.push_back(OTerm{outside, re, im});
-        }
-      };
+      const uint64_t bits = r->ctl_mask | (r->tgt >= 0 ? (1ull << r->tgt) : 0);
       const double d0r = r->g[0], d0i = r->g[1], d1r = r->g[6], d1i = r->g[7];
       if (r->tgt < 0) {
-        add_term(r->ctl_mask, d0r, d0i);
+        add_pending(r->ctl_mask, d0r, d0i);
       } else if (is_one(d0r, d0i)) {
-        add_term(bits, d1r, d1i);
+        add_pending(bits, d1r, d1i);
       } else {
-        add_term(r->ctl_mask, d0r, d0i);
+        add_pending(r->ctl_mask, d0r, d0i);
         const double den = d0r * d0r + d0i * d0i;  // != 0: see plan_diag()
-        const double qr = (d1r * d0r + d1i * d0i) / den, qi = (d1i * d0r - d1r * d0i) / den;
-        add_term(bits, qr, qi);
+        add_pending(bits, (d1r * d0r + d1i * d0i) / den, (d1i * d0r - d1r * d0i) / den);
       }
     }
-    // flush diag groups into the flat arrays
-    for (size_t k = 0; k < diag_op_ids.size(); ++k) {
-      SweepOp &op = sp->ops[diag_op_ids[k]];
-      op.group_off = (uint32_t)sp->groups.size();
-      for (auto &pg : diag_groups[k]) {
-        DGroup g{};
-        g.lane_mask = pg.lane; g.reg_mask = pg.reg; g.re = pg.re; g.im = pg.im;
-        g.oterm_off = (uint32_t)sp->oterms.size();
-        g.n_oterms = (uint32_t)pg.ot.size();
-        for (auto &t : pg.ot) sp->oterms.push_back(t);
-        sp->groups.push_back(g);
-      }
-      op.n_groups = (uint32_t)(sp->groups.size() - op.group_off);
+    flush_diag(&pending, ~0ull, sp);
+  }
+
+  static void cmul_acc(double *re, double *im, double fr, double fi) {
+    const double nr = *re * fr - *im * fi, ni = *re * fi + *im * fr;
+    *re = nr; *im = ni;
+  }
+
+  // Emit one DIAG op with every pending term touching `bits` (all terms when
+  // bits == ~0, including bit-less global factors).
+  void flush_diag(std::vector<PTerm> *pending, uint64_t bits, SweepPlan *sp) {
+    std::vector<PTerm> sel, keep;
+    for (auto &t : *pending) ((bits == ~0ull || (t.mask & bits)) ? sel : keep).push_back(t);
+    pending->swap(keep);
+    if (sel.empty()) return;
+    struct PGroup {
+      uint32_t lane, reg; double re = 1, im = 0;
+      std::vector<OTerm> single;  // single outside bit
+      std::vector<OTerm> multi;   // several outside bits
+    };
+    std::vector<PGroup> groups;
+    for (auto &t : sel) {
+      uint32_t lane, reg; uint64_t outside;
+      split_mask(*sp, t.mask, &lane, &reg, &outside);
+      PGroup *g = nullptr;
+      for (auto &pg : groups) if (pg.lane == lane && pg.reg == reg) { g = &pg; break; }
+      if (!g) { groups.push_back(PGroup{lane, reg}); g = &groups.back(); }
+      if (outside == 0) { cmul_acc(&g->re, &g->im, t.re, t.im); continue; }
+      auto &vec = (popc(outside) == 1) ? g->single : g->multi;
+      bool found = false;
+      for (auto &o : vec) if (o.mask == outside) { cmul_acc(&o.re, &o.im, t.re, t.im); found = true; break; }
+      if (!found) vec.push_back(OTerm{outside, t.re, t.im});
     }
+    SweepOp op{};
+    op.kind = OP_DIAG;
+    op.group_off = (uint32_t)sp->groups.size();
+    // (1) pure-lane groups (no outside terms) with equal reg_mask merge into one lane table
+    std::vector<bool> done(groups.size(), false);
+    for (size_t i = 0; i < groups.size(); ++i) {
+      if (done[i] || !groups[i].single.empty() || !groups[i].multi.empty()) continue;
+      std::vector<size_t> same;
+      for (size_t j = i; j < groups.size(); ++j)
+        if (!done[j] && groups[j].reg == groups[i].reg && groups[j].single.empty() && groups[j].multi.empty())
+          same.push_back(j);
+      if (same.size() < 2) continue;
+      DGroup g{};
+      g.reg_mask = groups[i].reg;
+      g.re = 1; g.im = 0;
+      g.flags = DG_LTAB;
+      g.ltab_off = (uint32_t)(sp->tables.size() / 2);
+      for (uint32_t lane = 0; lane < 64; ++lane) {
+        double fr = 1, fi = 0;
+        for (size_t j : same)
+          if ((lane & groups[j].lane) == groups[j].lane) cmul_acc(&fr, &fi, groups[j].re, groups[j].im);
+        sp->tables.push_back(fr);
+        sp->tables.push_back(fi);
+      }
+      for (size_t j : same) done[j] = true;
+      sp->groups.push_back(g);
+    }
+    // (2) the rest: one DGroup each; single-bit outside factors become chunk tables
+    for (size_t i = 0; i < groups.size(); ++i) {
+      if (done[i]) continue;
+      PGroup &pg = groups[i];
+      DGroup g{};
+      g.lane_mask = pg.lane; g.reg_mask = pg.reg; g.re = pg.re; g.im = pg.im;
+      std::vector<OTerm> loop_terms = pg.multi;
+      for (int shift = kLaneBits; shift < 64 && !pg.single.empty(); shift += 8) {
+        const uint64_t cmask = (shift + 8 >= 64) ? (~0ull << shift) : (((1ull << 8) - 1) << shift);
+        std::vector<OTerm> in;
+        for (auto &o : pg.single) if (o.mask & cmask) in.push_back(o);
+        if (in.empty()) continue;
+        if (g.ntab == 4 || in.size() < 2) {  // no table slot left / not worth a table
+          for (auto &o : in) loop_terms.push_back(o);
+          continue;
+        }
+        g.tab_shift |= (uint32_t)shift << (8 * g.ntab);
+        g.tab_off[g.ntab] = (uint32_t)(sp->tables.size() / 2);
+        g.ntab++;
+        for (uint32_t v = 0; v < 256; ++v) {
+          double fr = 1, fi = 0;
+          for (auto &o : in)
+            if (((uint64_t)v << shift) & o.mask) cmul_acc(&fr, &fi, o.re, o.im);
+          sp->tables.push_back(fr);
+          sp->tables.push_back(fi);
+        }
+      }
+      g.oterm_off = (uint32_t)sp->oterms.size();
+      g.n_oterms = (uint32_t)loop_terms.size();
+      for (auto &o : loop_terms) sp->oterms.push_back(o);
+      sp->groups.push_back(g);
+    }
+    op.n_groups = (uint32_t)(sp->groups.size() - op.group_off);
+    sp->ops.push_back(op);
   }
 };
 
@@ -351,7 +409,7 @@ inline std::string plan_to_json(const std::vector<GateRec> &queue, int nloc, uin
   Planner pl(nloc, shard, bw, max_rb);
   PlanResult pr = pl.plan(queue);
   std::string s = "{\"noop_gates\":" + std::to_string(pr.noop_gates) + ",\"sweeps\":[";
-  char buf[256];
+  char buf[384];
   for (size_t i = 0; i < pr.sweeps.size(); ++i) {
     const SweepPlan &sp = pr.sweeps[i];
     int nd = 0, ndiag = 0;
@@ -360,10 +418,10 @@ inline std::string plan_to_json(const std::vector<GateRec> &queue, int nloc, uin
     for (int k = 0; k < sp.rb; ++k) rp += (k ? "," : "") + std::to_string(sp.regpos[k]);
     rp += "]";
     snprintf(buf, sizeof buf,
-             "%s{\"gates\":%llu,\"dense_ops\":%d,\"diag_ops\":%d,\"groups\":%zu,\"oterms\":%zu,"
+             "%s{\"gates\":%llu,\"dense_ops\":%d,\"diag_ops\":%d,\"groups\":%zu,\"oterms\":%zu,\"table_entries\":%zu,"
              "\"regpos\":%s,\"fixed_ones\":%llu,\"ntiles\":%llu,\"alg_bytes\":%llu,\"swept_bytes\":%llu}",
              i ? "," : "", (unsigned long long)sp.gates, nd, ndiag, sp.groups.size(), sp.oterms.size(),
-             rp.c_str(), (unsigned long long)sp.fixed_ones, (unsigned long long)sp.ntiles,
+             sp.tables.size() / 2, rp.c_str(), (unsigned long long)sp.fixed_ones, (unsigned long long)sp.ntiles,
              (unsigned long long)sp.alg_bytes, (unsigned long long)sp.swept_bytes);
     s += buf;
   }

@@ -54,8 +54,9 @@ def L(name):
 
 
 def cmul_pair(a, slots, fr, fi):
-  """slot *= (fr,fi) for 1 or 2 slots, interleaved; temps v[28:29], v[30:31]."""
-  tmps = ['v[28:29]', 'v[30:31]']
+  """slot *= (fr,fi) for 1..4 slots, interleaved; temps v[28:35]."""
+  tmps = ['v[28:29]', 'v[30:31]', 'v[32:33]', 'v[34:35]']
+  assert len(slots) <= 4
   for t, k in zip(tmps, slots):
     a(f'v_mul_f64 {t}, {X(k)}, {fr}')
   for t, k in zip(tmps, slots):
@@ -68,6 +69,15 @@ def cmul_pair(a, slots, fr, fi):
     a(f'v_mov_b64 {X(k)}, {t}')
 
 
+def cmul_uniform(a, ure, uim, sre, sim, tmp='v[28:29]'):
+  """(ure,uim) *= (sre,sim): VGPR-held wave-uniform value times SGPR pair."""
+  a(f'v_mul_f64 {tmp}, {ure}, {sre}')
+  a(f'v_fma_f64 {tmp}, -{uim}, {sim}, {tmp}')
+  a(f'v_mul_f64 {uim}, {uim}, {sre}')
+  a(f'v_fma_f64 {uim}, {ure}, {sim}, {uim}')
+  a(f'v_mov_b64 {ure}, {tmp}')
+
+
 def gen(rb):
   nr = 1 << rb
   a = Asm()
@@ -75,7 +85,7 @@ def gen(rb):
   # ---- prologue: parameters -------------------------------------------------
   a('s_load_dwordx4 s[36:39], %2, 0x0')   # ops cursor, groups base
   a('s_load_dwordx2 s[40:41], %2, 0x10')  # oterms base
-  a('s_load_dword s42, %2, 0x18')         # nops
+  a('s_load_dwordx2 s[42:43], %2, 0x18')  # s42 = ops remaining, s43 = tables - groups (bytes)
   # ---- load the tile: one 1-KiB global_load_dwordx4 per slot ----------------
   for j in range(nr // batch):
     a(f's_load_dwordx{2 * batch} s[52:{52 + 2 * batch - 1}], %2, {0x40 + 8 * batch * j}')
@@ -85,11 +95,10 @@ def gen(rb):
       a(f's_add_u32 s98, %0, s{52 + 2 * i}')
       a(f's_addc_u32 s99, %1, s{53 + 2 * i}')
       a(f'global_load_dwordx4 v[{T(k)}:{T(k) + 3}], %4, s[98:99]')
-  a('s_mov_b32 s43, 0')
   a('s_waitcnt vmcnt(0)')
   # ---- op loop ------------------------------------------------------------------
   a.label('L_op')
-  a('s_cmp_ge_u32 s43, s42')
+  a('s_cmp_eq_u32 s42, 0')
   a(f's_cbranch_scc1 {L("L_done")}')
   a('s_load_dwordx8 s[44:51], s[36:37], 0x0')    # kind tb cm_reg n_groups cm_thread(2) group_off pad
   a('s_load_dwordx16 s[52:67], s[36:37], 0x20')  # g[8]
@@ -111,7 +120,7 @@ def gen(rb):
   a.label('L_next')
   a('s_add_u32 s36, s36, 96')
   a('s_addc_u32 s37, s37, 0')
-  a('s_add_u32 s43, s43, 1')
+  a('s_sub_u32 s42, s42, 1')
   a(f's_branch {L("L_op")}')
 
   # ---- dense 2x2 on register bit b: in-place butterflies --------------------------
@@ -217,6 +226,9 @@ def gen(rb):
   a(f's_branch {L("L_next")}')
 
   # ---- diagonal op: groups of phase factors -------------------------------------------
+  # SGPRs here: s[48:49] tables base, s[52:67] group header (lane_mask reg_mask
+  # oterm_off n_oterms re(2) im(2) flags ltab_off ntab tab_shift tab_off[4]),
+  # s[76:91] chunk-table entries / oterm scratch, s[92:93] group cursor, s96 counter.
   a.label('L_diag')
   a('v_mov_b32 v20, 0')
   a('v_mov_b32 v21, 0x3ff00000')   # c = 1.0 + 0.0i  (cr = v[20:21], ci = v[22:23])
@@ -225,20 +237,49 @@ def gen(rb):
   a('s_mov_b32 s75, 0')            # c modified?
   a('s_cmp_eq_u32 s47, 0')
   a(f's_cbranch_scc1 {L("L_next")}')
-  a('s_lshl_b32 s74, s50, 5')      # group_off * sizeof(DGroup)=32
+  a('s_add_u32 s48, s38, s43')     # tables base = groups base + rel
+  a('s_addc_u32 s49, s39, 0')
+  a('s_lshl_b32 s74, s50, 6')      # group_off * sizeof(DGroup)=64
   a('s_add_u32 s92, s38, s74')
   a('s_addc_u32 s93, s39, 0')
   a('s_mov_b32 s96, 0')
   a.label('L_grp')
-  a('s_load_dwordx8 s[76:83], s[92:93], 0x0')  # lane_mask reg_mask oterm_off n_oterms re(2) im(2)
+  a('s_load_dwordx16 s[52:67], s[92:93], 0x0')
   a('s_waitcnt lgkmcnt(0)')
-  a('v_mov_b32 v24, s80')
-  a('v_mov_b32 v25, s81')          # u = v[24:25] + i v[26:27]  (wave-uniform value)
-  a('v_mov_b32 v26, s82')
-  a('v_mov_b32 v27, s83')
-  a('s_cmp_eq_u32 s79, 0')
+  a('v_mov_b32 v24, s56')
+  a('v_mov_b32 v25, s57')          # u = v[24:25] + i v[26:27]  (wave-uniform value)
+  a('v_mov_b32 v26, s58')
+  a('v_mov_b32 v27, s59')
+  a('s_bitcmp1_b32 s60, 0')        # LTAB: start the 1-KiB lane-table load early
+  a(f's_cbranch_scc0 {L("L_g1")}')
+  a('s_lshl_b32 s74, s61, 4')
+  a('s_add_u32 s98, s48, s74')
+  a('s_addc_u32 s99, s49, 0')
+  a('global_load_dwordx4 v[40:43], %4, s[98:99]')
+  a.label('L_g1')
+  a('s_cmp_eq_u32 s62, 0')
+  a(f's_cbranch_scc1 {L("L_g2")}')
+  for t in range(4):               # issue all chunk-table lookups, then one wait
+    if t:
+      a(f's_cmp_le_u32 s62, {t}')
+      a(f's_cbranch_scc1 {L("L_g1w")}')
+    a(f's_bfe_u32 s74, s63, {(8 << 16) | (8 * t)}')
+    a('s_lshr_b64 s[72:73], %3, s74')
+    a('s_and_b32 s72, s72, 0xff')
+    a(f's_add_u32 s72, s72, s{64 + t}')
+    a('s_lshl_b32 s72, s72, 4')
+    a(f's_load_dwordx4 s[{76 + 4 * t}:{79 + 4 * t}], s[48:49], s72')
+  a.label('L_g1w')
+  a('s_waitcnt lgkmcnt(0)')
+  for t in range(4):
+    if t:
+      a(f's_cmp_le_u32 s62, {t}')
+      a(f's_cbranch_scc1 {L("L_g2")}')
+    cmul_uniform(a, 'v[24:25]', 'v[26:27]', f's[{76 + 4 * t}:{77 + 4 * t}]', f's[{78 + 4 * t}:{79 + 4 * t}]')
+  a.label('L_g2')
+  a('s_cmp_eq_u32 s55, 0')
   a(f's_cbranch_scc1 {L("L_grp_f")}')
-  a('s_mul_i32 s74, s78, 24')      # oterm_off * sizeof(OTerm)=24
+  a('s_mul_i32 s74, s54, 24')      # oterm_off * sizeof(OTerm)=24
   a('s_add_u32 s94, s40, s74')
   a('s_addc_u32 s95, s41, 0')
   a('s_mov_b32 s97, 0')
@@ -246,32 +287,38 @@ def gen(rb):
   a('s_load_dwordx2 s[84:85], s[94:95], 0x0')
   a('s_load_dwordx4 s[88:91], s[94:95], 0x8')
   a('s_waitcnt lgkmcnt(0)')
-  a('s_and_b64 s[86:87], %3, s[84:85]')
-  a('s_cmp_eq_u64 s[86:87], s[84:85]')
+  a('s_and_b64 s[72:73], %3, s[84:85]')
+  a('s_cmp_eq_u64 s[72:73], s[84:85]')
   a(f's_cbranch_scc0 {L("L_ot_n")}')
-  a('v_mul_f64 v[28:29], v[24:25], s[88:89]')
-  a('v_fma_f64 v[28:29], -v[26:27], s[90:91], v[28:29]')
-  a('v_mul_f64 v[26:27], v[26:27], s[88:89]')
-  a('v_fma_f64 v[26:27], v[24:25], s[90:91], v[26:27]')
-  a('v_mov_b64 v[24:25], v[28:29]')
+  cmul_uniform(a, 'v[24:25]', 'v[26:27]', 's[88:89]', 's[90:91]')
   a.label('L_ot_n')
   a('s_add_u32 s94, s94, 24')
   a('s_addc_u32 s95, s95, 0')
   a('s_add_u32 s97, s97, 1')
-  a('s_cmp_lt_u32 s97, s79')
+  a('s_cmp_lt_u32 s97, s55')
   a(f's_cbranch_scc1 {L("L_ot")}')
   a.label('L_grp_f')
-  # f = lane_ok ? u : 1   (fr = v[58:59], fi = v[60:61])
-  a('v_and_b32 v16, s76, %5')
-  a('v_cmp_eq_u32 vcc, s76, v16')
+  # per-lane factor f (fr = v[58:59], fi = v[60:61])
+  a('s_bitcmp1_b32 s60, 0')
+  a(f's_cbranch_scc0 {L("L_g3")}')
+  a('s_waitcnt vmcnt(0)')          # f = ltab[lane] * u
+  a('v_mul_f64 v[58:59], v[40:41], v[24:25]')
+  a('v_mul_f64 v[60:61], v[40:41], v[26:27]')
+  a('v_fma_f64 v[58:59], -v[42:43], v[26:27], v[58:59]')
+  a('v_fma_f64 v[60:61], v[42:43], v[24:25], v[60:61]')
+  a(f's_branch {L("L_g4")}')
+  a.label('L_g3')                  # f = lane_ok ? u : 1
+  a('v_and_b32 v16, s52, %5')
+  a('v_cmp_eq_u32 vcc, s52, v16')
   a('v_mov_b32 v17, 0x3ff00000')
   a('v_cndmask_b32 v58, 0, v24, vcc')
   a('v_cndmask_b32 v59, v17, v25, vcc')
   a('v_cndmask_b32 v60, 0, v26, vcc')
   a('v_cndmask_b32 v61, 0, v27, vcc')
-  a('s_cmp_eq_u32 s77, 0')
+  a.label('L_g4')
+  a('s_cmp_eq_u32 s53, 0')
   a(f's_cbranch_scc0 {L("L_grp_r")}')
-  # c *= f
+  # reg_mask == 0: c *= f
   a('v_mul_f64 v[28:29], v[20:21], v[58:59]')
   a('v_fma_f64 v[28:29], -v[22:23], v[60:61], v[28:29]')
   a('v_mul_f64 v[22:23], v[22:23], v[58:59]')
@@ -280,23 +327,34 @@ def gen(rb):
   a('s_mov_b32 s75, 1')
   a(f's_branch {L("L_grp_n")}')
   a.label('L_grp_r')
-  for k in range(nr):
+  for b in range(rb):              # single register bit: straight-line, no per-slot branches
+    a(f's_cmp_eq_u32 s53, {1 << b}')
+    a(f's_cbranch_scc1 {L(f"L_gsb{b}")}')
+  for k in range(nr):              # general register mask
     skip = f'L_g_{k}'
-    a(f's_andn2_b32 s74, s77, {k}')
+    a(f's_andn2_b32 s74, s53, {k}')
     a('s_cmp_eq_u32 s74, 0')
     a(f's_cbranch_scc0 {L(skip)}')
     cmul_pair(a, [k], 'v[58:59]', 'v[60:61]')
     a.label(skip)
+  a(f's_branch {L("L_grp_n")}')
+  for b in range(rb):
+    a.label(f'L_gsb{b}')
+    slots = [k for k in range(nr) if (k >> b) & 1]
+    for i in range(0, len(slots), 4):
+      cmul_pair(a, slots[i:i + 4], 'v[58:59]', 'v[60:61]')
+    if b != rb - 1:
+      a(f's_branch {L("L_grp_n")}')
   a.label('L_grp_n')
-  a('s_add_u32 s92, s92, 32')
+  a('s_add_u32 s92, s92, 64')
   a('s_addc_u32 s93, s93, 0')
   a('s_add_u32 s96, s96, 1')
   a('s_cmp_lt_u32 s96, s47')
   a(f's_cbranch_scc1 {L("L_grp")}')
   a('s_cmp_eq_u32 s75, 0')
   a(f's_cbranch_scc1 {L("L_next")}')
-  for k in range(0, nr, 2):
-    cmul_pair(a, [k, k + 1], 'v[20:21]', 'v[22:23]')
+  for k in range(0, nr, 4):
+    cmul_pair(a, list(range(k, min(k + 4, nr))), 'v[20:21]', 'v[22:23]')
   a(f's_branch {L("L_next")}')
 
   # ---- store the tile ----------------------------------------------------------------------
