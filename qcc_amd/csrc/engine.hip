@@ -103,31 +103,65 @@ unsigned pick_grid(uint64_t nwork, int per_block) {
   return (unsigned)blocks;
 }
 
-template <typename R>
-void launch_pair(qh_state_s *h, uint64_t nwork, int p, const qh::BitIns &ins, const double g[8]) {
+int env_int(const char *name, int dflt) {
+  const char *s = getenv(name);
+  return s ? atoi(s) : dflt;
+}
+// Launch shape of the per-gate kernels (tools/membench on MI355X): small blocks
+// of work, one chunk per block (no grid-stride), non-temporal access.
+int gate_u() { static int v = env_int("QH_GATE_U", 1); return v; }
+bool gate_nt() { static int v = env_int("QH_GATE_NT", 1); return v != 0; }
+
+template <typename R, int U, bool NT>
+void launch_pair_u(qh_state_s *h, uint64_t nwork, int p, const qh::BitIns &ins, const double g[8]) {
   using A = typename qh::AmpT<R>::type;
-  constexpr int U = 4;
   const unsigned grid = pick_grid(nwork, 256 * U);
   if (nwork % (256 * U) == 0)
-    hipLaunchKernelGGL((qh::k_pair<R, U, false>), dim3(grid), dim3(256), 0, h->stream,
+    hipLaunchKernelGGL((qh::k_pair<R, U, false, NT>), dim3(grid), dim3(256), 0, h->stream,
                        (A *)h->d_psi, nwork, p, ins, to_gate<R>(g));
   else
-    hipLaunchKernelGGL((qh::k_pair<R, U, true>), dim3(grid), dim3(256), 0, h->stream,
+    hipLaunchKernelGGL((qh::k_pair<R, U, true, NT>), dim3(grid), dim3(256), 0, h->stream,
                        (A *)h->d_psi, nwork, p, ins, to_gate<R>(g));
 }
-
 template <typename R>
-void launch_diag(qh_state_s *h, uint64_t nwork, int sel, const qh::BitIns &ins, double f0r,
-                 double f0i, double f1r, double f1i) {
+void launch_pair(qh_state_s *h, uint64_t nwork, int p, const qh::BitIns &ins, const double g[8]) {
+  const int u = gate_u();
+  if (gate_nt()) {
+    if (u >= 4) launch_pair_u<R, 4, true>(h, nwork, p, ins, g);
+    else if (u == 2) launch_pair_u<R, 2, true>(h, nwork, p, ins, g);
+    else launch_pair_u<R, 1, true>(h, nwork, p, ins, g);
+  } else {
+    if (u >= 4) launch_pair_u<R, 4, false>(h, nwork, p, ins, g);
+    else if (u == 2) launch_pair_u<R, 2, false>(h, nwork, p, ins, g);
+    else launch_pair_u<R, 1, false>(h, nwork, p, ins, g);
+  }
+}
+
+template <typename R, int U, bool NT>
+void launch_diag_u(qh_state_s *h, uint64_t nwork, int sel, const qh::BitIns &ins, double f0r, double f0i,
+                   double f1r, double f1i) {
   using A = typename qh::AmpT<R>::type;
-  constexpr int U = 4;
   const unsigned grid = pick_grid(nwork, 256 * U);
   if (nwork % (256 * U) == 0)
-    hipLaunchKernelGGL((qh::k_diag<R, U, false>), dim3(grid), dim3(256), 0, h->stream,
+    hipLaunchKernelGGL((qh::k_diag<R, U, false, NT>), dim3(grid), dim3(256), 0, h->stream,
                        (A *)h->d_psi, nwork, sel, ins, (R)f0r, (R)f0i, (R)f1r, (R)f1i);
   else
-    hipLaunchKernelGGL((qh::k_diag<R, U, true>), dim3(grid), dim3(256), 0, h->stream,
+    hipLaunchKernelGGL((qh::k_diag<R, U, true, NT>), dim3(grid), dim3(256), 0, h->stream,
                        (A *)h->d_psi, nwork, sel, ins, (R)f0r, (R)f0i, (R)f1r, (R)f1i);
+}
+template <typename R>
+void launch_diag(qh_state_s *h, uint64_t nwork, int sel, const qh::BitIns &ins, double f0r, double f0i,
+                 double f1r, double f1i) {
+  const int u = gate_u() * 2;  // a diagonal work item is one amplitude, a pair item two
+  if (gate_nt()) {
+    if (u >= 4) launch_diag_u<R, 4, true>(h, nwork, sel, ins, f0r, f0i, f1r, f1i);
+    else if (u == 2) launch_diag_u<R, 2, true>(h, nwork, sel, ins, f0r, f0i, f1r, f1i);
+    else launch_diag_u<R, 1, true>(h, nwork, sel, ins, f0r, f0i, f1r, f1i);
+  } else {
+    if (u >= 4) launch_diag_u<R, 4, false>(h, nwork, sel, ins, f0r, f0i, f1r, f1i);
+    else if (u == 2) launch_diag_u<R, 2, false>(h, nwork, sel, ins, f0r, f0i, f1r, f1i);
+    else launch_diag_u<R, 1, false>(h, nwork, sel, ins, f0r, f0i, f1r, f1i);
+  }
 }
 
 // One gate, physical bit positions, one kernel.  Returns QH_* status.

@@ -10,7 +10,7 @@ import subprocess
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
-LIB_PATH = os.path.join(PKG, 'libqcc_hip.so')
+LIB_PATH = os.environ.get('QCC_HIP_LIB') or os.path.join(PKG, 'libqcc_hip.so')  # env: A/B builds only
 SOURCES = [os.path.join(PKG, 'csrc', f) for f in
            ('engine.hip', 'kernels_gate.hip.h', 'kernels_sweep.hip.h', 'planner.h',
             'sweep_island_rb2.inc', 'sweep_island_rb3.inc', 'sweep_island_rb4.inc',

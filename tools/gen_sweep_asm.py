@@ -24,6 +24,8 @@ import os
 import sys
 
 OP_DENSE_REG, OP_DENSE_LANE, OP_DIAG = 0, 1, 2
+# streaming tile loads/stores are non-temporal (each byte is touched once per sweep)
+NT = '' if os.environ.get('QH_ISLAND_NT', '1') == '0' else ' nt'
 
 
 def T(k):
@@ -94,7 +96,7 @@ def gen(rb):
       k = batch * j + i
       a(f's_add_u32 s98, %0, s{52 + 2 * i}')
       a(f's_addc_u32 s99, %1, s{53 + 2 * i}')
-      a(f'global_load_dwordx4 v[{T(k)}:{T(k) + 3}], %4, s[98:99]')
+      a(f'global_load_dwordx4 v[{T(k)}:{T(k) + 3}], %4, s[98:99]' + NT)
   a('s_waitcnt vmcnt(0)')
   # ---- op loop ------------------------------------------------------------------
   a.label('L_op')
@@ -366,7 +368,7 @@ def gen(rb):
       k = batch * j + i
       a(f's_add_u32 s98, %0, s{52 + 2 * i}')
       a(f's_addc_u32 s99, %1, s{53 + 2 * i}')
-      a(f'global_store_dwordx4 %4, v[{T(k)}:{T(k) + 3}], s[98:99]')
+      a(f'global_store_dwordx4 %4, v[{T(k)}:{T(k) + 3}], s[98:99]' + NT)
   a('s_nop 0')
 
   clob = [f'v{i}' for i in range(16, 64 + 4 * nr)] + [f's{i}' for i in range(36, 100)] + ['vcc', 'scc', 'memory']
