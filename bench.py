@@ -55,6 +55,22 @@ def class_pass(st, ops, g8, sel, reps):
   return ms / launches, launches // reps, s['bytes_swept'] / launches, s['bytes_algorithmic'] / launches
 
 
+def pmc_traffic(kernel_substr, fused):
+  """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC
+  passes (profiles/rNN/traffic_*.json, produced by tools/collect_traffic.py on
+  this same bench command).  None when no pass has been committed."""
+  import glob
+  name = 'traffic_fused.json' if fused else 'traffic_unfused.json'
+  files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*', name)))
+  if not files:
+    return None, None
+  d = json.load(open(files[-1]))
+  for k, v in d['kernels'].items():
+    if kernel_substr in k:
+      return v['hbm_bytes'], os.path.relpath(files[-1], ROOT)
+  return None, None
+
+
 def cpu_baseline(args, ops, g8):
   """Reference xgates.cc build (oracle/_ref) if it travelled, else our C port,
   single thread, on a bounded sample of the same stream."""
@@ -190,9 +206,10 @@ def main():
         bytes_l = stats['bytes_swept'] / launches
         other = {}
       achieved = bytes_l / (ms_l * 1e-3) / 1e9
+      traffic, tsrc = pmc_traffic(name.split(' ')[0], fusion != native.QH_FUSE_OFF)
       roofline = {'bound': 'hbm', 'kernel': name, 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                  'frac': achieved / HBM_PEAK_GBPS, 'traffic': None, 'avg_launch_ms': ms_l,
-                  'bytes_per_launch': bytes_l, 'classes': other}
+                  'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic, 'traffic_source': tsrc,
+                  'avg_launch_ms': ms_l, 'bytes_per_launch': bytes_l, 'classes': other}
     else:
       roofline = {'bound': 'hbm', 'achieved': stats['bytes_swept'] / (ev_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBPS,
                   'unit': 'GB/s', 'frac': stats['bytes_swept'] / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
