@@ -124,6 +124,7 @@ int qh_logical_to_phys(qh_handle h, uint64_t logical_index, uint64_t *phys);
 int qh_norm2(qh_handle h, double *out);                       /* sum |a|^2 of the shard */
 int qh_argmax(qh_handle h, uint64_t *phys_index, double *prob); /* max |a|^2 of the shard */
 int qh_prob_bit(qh_handle h, int logical_bit, double *p1);    /* sum |a|^2 with bit set (shard) */
+int qh_prob_bit_value(qh_handle h, int logical_bit, int value, double *p); /* ... with bit == value */
 int qh_scale(qh_handle h, double re, double im);              /* a *= (re + i im) */
 /* Project on logical_bit == value (zero the rest); caller renormalises with qh_scale. */
 int qh_project_bit(qh_handle h, int logical_bit, int value);

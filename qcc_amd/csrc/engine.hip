@@ -630,44 +630,48 @@ int qh_norm2(qh_handle h, double *out) {
   const unsigned grid = (unsigned)std::min<uint64_t>((n + 255) / 256, 4096);
   if (h->bw == 128)
     hipLaunchKernelGGL(qh::k_norm2<double>, dim3(grid), dim3(256), 0, h->stream,
-                       (const double2 *)h->d_psi, n, 0ull, h->d_red);
+                       (const double2 *)h->d_psi, n, 0ull, 0ull, h->d_red);
   else
     hipLaunchKernelGGL(qh::k_norm2<float>, dim3(grid), dim3(256), 0, h->stream,
-                       (const float2 *)h->d_psi, n, 0ull, h->d_red);
+                       (const float2 *)h->d_psi, n, 0ull, 0ull, h->d_red);
   HIP_TRY(hipMemcpyAsync(out, h->d_red, sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   return QH_OK;
 }
 
-int qh_prob_bit(qh_handle h, int logical_bit, double *p1) {
-  if (!h || !p1 || h->dry) return fail(QH_ERR_ARG, "null/dry");
+int qh_prob_bit_value(qh_handle h, int logical_bit, int value, double *p) {
+  if (!h || !p || h->dry) return fail(QH_ERR_ARG, "null/dry");
   if (logical_bit < 0 || logical_bit >= h->nglob) return fail(QH_ERR_BAD_QUBIT, "bit %d", logical_bit);
   HIP_TRY(hipSetDevice(h->device));
   int rc = flush_impl(h);
   if (rc) return rc;
+  value = value ? 1 : 0;
   const int pb = h->perm[logical_bit];
-  uint64_t mask = 0;
+  uint64_t mask = 0, want = 0;
   if (pb >= h->nloc) {
-    if (!((h->shard >> (pb - h->nloc)) & 1ull)) {
-      *p1 = 0.0;
+    if ((int)((h->shard >> (pb - h->nloc)) & 1ull) != value) {
+      *p = 0.0;
       return QH_OK;
     }
   } else {
     mask = 1ull << pb;
+    want = value ? mask : 0;
   }
   HIP_TRY(hipMemsetAsync(h->d_red, 0, sizeof(double), h->stream));
   const uint64_t n = 1ull << h->nloc;
   const unsigned grid = (unsigned)std::min<uint64_t>((n + 255) / 256, 4096);
   if (h->bw == 128)
     hipLaunchKernelGGL(qh::k_norm2<double>, dim3(grid), dim3(256), 0, h->stream,
-                       (const double2 *)h->d_psi, n, mask, h->d_red);
+                       (const double2 *)h->d_psi, n, mask, want, h->d_red);
   else
     hipLaunchKernelGGL(qh::k_norm2<float>, dim3(grid), dim3(256), 0, h->stream,
-                       (const float2 *)h->d_psi, n, mask, h->d_red);
-  HIP_TRY(hipMemcpyAsync(p1, h->d_red, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+                       (const float2 *)h->d_psi, n, mask, want, h->d_red);
+  HIP_TRY(hipMemcpyAsync(p, h->d_red, sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   return QH_OK;
 }
+
+int qh_prob_bit(qh_handle h, int logical_bit, double *p1) { return qh_prob_bit_value(h, logical_bit, 1, p1); }
 
 int qh_argmax(qh_handle h, uint64_t *phys_index, double *prob) {
   if (!h || !phys_index || !prob || h->dry) return fail(QH_ERR_ARG, "null/dry");

@@ -174,15 +174,15 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-// out[0] += sum |a|^2 over indices having all bits of `mask` set (mask==0: all).
+// out[0] += sum |a|^2 over indices i with (i & mask) == want (mask==0: all).
 template <typename R>
 __global__ __launch_bounds__(256) void k_norm2(const typename AmpT<R>::type *__restrict__ psi,
-                                                uint64_t n, uint64_t mask, double *out) {
+                                                uint64_t n, uint64_t mask, uint64_t want, double *out) {
   __shared__ double part[4];
   double acc = 0.0;
   for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n;
        i += (uint64_t)gridDim.x * 256) {
-    if ((i & mask) == mask) {
+    if ((i & mask) == want) {
       const auto a = psi[i];
       acc += (double)a.x * (double)a.x + (double)a.y * (double)a.y;
     }

@@ -133,9 +133,9 @@ class DeviceState:
     native.check(self.lib.qh_argmax(self.h, ctypes.byref(i), ctypes.byref(p)))
     return self.phys_to_logical(i.value), p.value
 
-  def prob_bit(self, logical_bit):
+  def prob_bit(self, logical_bit, value=1):
     v = ctypes.c_double()
-    native.check(self.lib.qh_prob_bit(self.h, int(logical_bit), ctypes.byref(v)))
+    native.check(self.lib.qh_prob_bit_value(self.h, int(logical_bit), int(value), ctypes.byref(v)))
     return v.value
 
   def scale(self, z):

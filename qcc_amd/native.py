@@ -62,6 +62,7 @@ SIGNATURES = {
     'qh_norm2': (_i32, [_vp, _dp]),
     'qh_argmax': (_i32, [_vp, ctypes.POINTER(_u64), _dp]),
     'qh_prob_bit': (_i32, [_vp, _i32, _dp]),
+    'qh_prob_bit_value': (_i32, [_vp, _i32, _i32, _dp]),
     'qh_scale': (_i32, [_vp, ctypes.c_double, ctypes.c_double]),
     'qh_project_bit': (_i32, [_vp, _i32, _i32]),
     'qh_get_stats': (_i32, [_vp, ctypes.POINTER(QhStats)]),

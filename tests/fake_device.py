@@ -1,0 +1,84 @@
+"""TEST-ONLY stand-ins for the GPU, used by the CPU ("not gpu") host-logic tests.
+
+OracleDevice implements the interface circuit.qc needs from
+qcc_amd.device.DeviceState with NumPy + the CPU oracle; OracleHostExecutor is
+the host-buffer counterpart.  Installed through qcc_amd.lib.backend's test
+seams; product code never imports this module.
+"""
+import numpy as np
+
+from tests import oracle_lib
+
+
+class OracleDevice:
+  calls = 0
+
+  def __init__(self, nbits, bit_width):
+    self.nbits, self.bit_width = nbits, bit_width
+    self.dtype = np.complex128 if bit_width == 128 else np.complex64
+    self.psi = np.zeros(1 << nbits, dtype=self.dtype)
+    self.o = oracle_lib.load()
+    self.trace = []
+
+  def close(self):
+    pass
+
+  def init_basis(self, index=0):
+    self.psi[:] = 0
+    self.psi[index] = 1
+
+  def upload(self, host, offset=0):
+    host = np.asarray(host, dtype=self.dtype)
+    self.psi[offset:offset + host.size] = host
+
+  def download(self, offset=0, count=None, out=None):
+    count = self.psi.size - offset if count is None else count
+    return self.psi[offset:offset + count].copy()
+
+  def apply1(self, gate, index):
+    OracleDevice.calls += 1
+    self.trace.append((None, int(index), np.asarray(gate, dtype=np.complex128).reshape(4).copy()))
+    self.o.apply1(self.psi, gate, self.nbits, index)
+
+  def applyc(self, gate, control, target):
+    OracleDevice.calls += 1
+    self.trace.append((int(control), int(target), np.asarray(gate, dtype=np.complex128).reshape(4).copy()))
+    self.o.applyc(self.psi, gate, self.nbits, control, target)
+
+  def sync(self):
+    pass
+
+  def flush(self):
+    pass
+
+  def norm2(self):
+    return float(np.vdot(self.psi, self.psi).real)
+
+  def argmax(self):
+    i = int(np.argmax(np.abs(self.psi)))
+    return i, float(np.abs(self.psi[i]) ** 2)
+
+  def prob_bit(self, bit, value=1):
+    sel = ((np.arange(self.psi.size) >> bit) & 1) == value
+    return float(np.vdot(self.psi[sel], self.psi[sel]).real)
+
+  def project_bit(self, bit, value):
+    sel = ((np.arange(self.psi.size) >> bit) & 1) != value
+    self.psi[sel] = 0
+
+  def scale(self, z):
+    self.psi *= z
+
+  def amplitude(self, index):
+    return self.psi[index]
+
+
+class OracleHostExecutor:
+  def __init__(self):
+    self.o = oracle_lib.load()
+
+  def apply1(self, psi, gate, nbits, tgt, bit_width=128):
+    self.o.apply1(psi, gate, nbits, tgt)
+
+  def applyc(self, psi, gate, nbits, ctl, tgt, bit_width=128):
+    self.o.applyc(psi, gate, nbits, ctl, tgt)

@@ -1,0 +1,157 @@
+"""GPU tests of the host API mirror on the real engine (no stand-ins): the
+reference's circuits re-issued through qcc_amd.lib.circuit.qc run on the MI355X
+and reproduce the reference's golden final states."""
+import importlib
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from qcc_amd import native, workloads
+from qcc_amd.lib import backend, circuit, ops, state, tensor
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(autouse=True)
+def width128():
+  backend.set_device_factory(None)
+  backend.set_host_executor(None)
+  tensor.set_tensor_width(128)
+  yield
+  tensor.set_tensor_width(None)
+
+
+def test_qc_qft12_config1(golden_dir):
+  g = np.load(os.path.join(golden_dir, 'g1_qft12.npz'))
+  qc = circuit.qc('qft12')
+  reg = qc.reg(12, tuple(int(b) for b in g['bits']))
+  qc.qft(reg)
+  assert np.max(np.abs(qc.psi - g['final'])) <= 1e-10       # BASELINE config 1, vs reference xgates
+  g2 = np.load(os.path.join(golden_dir, 'g2_libq_qft12.npz'))  # and vs reference libq (float)
+  dense = np.zeros(1 << 12, dtype=np.complex128)
+  for s, a in zip(g2['libq_state'], g2['amp']):
+    dense[int(format(int(s), '012b')[::-1], 2)] = a
+  assert np.max(np.abs(qc.psi - dense)) < 2e-6
+  assert type(qc._dev).__module__ == 'qcc_amd.device'       # really the HIP engine
+
+
+def test_qc_composites_match_reference(golden_dir):
+  g = np.load(os.path.join(golden_dir, 'g5_multi_control.npz'))
+  qc = circuit.qc('mc')
+  qc.reg(4, (1, 0, 1, 1))
+  aux = qc.reg(4, 0)
+  qc.h([0, 1, 2, 3])
+  qc.multi_control([0, [1], 2], 3, aux, ops.PauliX(), 'mc-x')
+  qc.multi_control([0, 1, [2], 3], 7, aux, ops.Hadamard(), 'mc-h')
+  qc.cswap(0, 1, 2)
+  qc.swap(0, 3)
+  qc.ccu1(0, 1, 2, 0.77)
+  qc.crx(1, 2, 0.3); qc.cry([0], 3, 0.4); qc.crz(3, 0, 0.5)
+  assert np.max(np.abs(qc.psi - g['final'])) <= 1e-12
+
+
+def test_grover_circuit_reference_and_recurrence(golden_dir):
+  """grover.py:124-168 through qc (nbits=6 -> 12 qubits): reference golden state,
+  the 4-amplitude recurrence and the device-side maxprob."""
+  g = np.load(os.path.join(golden_dir, 'g5_grover6.npz'))
+  nb, bits = 6, [int(b) for b in g['marked']]
+  qc = circuit.qc('Grover')
+  reg = qc.reg(nb, 0)
+  qc.reg(1, 1)
+  aux = qc.reg(nb - 1, 0)
+  its = int(math.pi / 4 * math.sqrt(2 ** nb))
+  qc.h(list(range(nb + 1)))
+  idx = list(range(nb))
+  for _ in range(its):
+    for i in idx:
+      if bits[i] == 0:
+        qc.apply1(ops.PauliX(), i, 'x')
+    qc.multi_control(reg, nb, aux, ops.PauliX(), 'Phase Inversion')
+    for i in idx:
+      if bits[i] == 0:
+        qc.apply1(ops.PauliX(), i, 'x')
+    qc.h(idx); qc.x(idx)
+    qc.multi_control(reg, nb, aux, ops.PauliZ(), 'Mean Inversion')
+    qc.x(idx); qc.h(idx)
+  maxbits, maxprob = qc.maxprob()                     # device-side argmax
+  assert maxbits[:nb] == bits
+  psi = qc.psi
+  assert np.max(np.abs(psi - g['final'])) <= 1e-10
+  cm0, cm1, cu0, cu1 = workloads.grover_recurrence(nb, its)
+  x = int(''.join(map(str, bits)), 2)
+  other = (x + 1) % (1 << nb)
+  for xx, (c0, c1) in ((x, (cm0, cm1)), (other, (cu0, cu1))):
+    assert abs(psi[(xx << nb) | 0] - c0) < 1e-12 and abs(psi[(xx << nb) | (1 << (nb - 1))] - c1) < 1e-12
+  assert abs(maxprob - max(cm0 ** 2, cm1 ** 2)) < 1e-12
+
+
+def test_state_methods_run_on_gpu(golden_dir):
+  g = np.load(os.path.join(golden_dir, 'py_fallback.npz'))
+  psi = state.bitstring(1, 0, 1, 0, 1)
+  for (c, t), gate in zip(g['ops'], g['gates'].view(np.complex128).reshape(-1, 2, 2)):
+    if c == -(2 ** 31):
+      psi.apply1(ops.Operator(gate), int(t))
+    else:
+      psi.applyc(ops.Operator(gate), int(c), int(t))      # includes the negative-control calls
+  assert np.max(np.abs(psi - g['final'])) < 1e-13
+
+
+def test_libxgates_dropin_module(oracle):
+  sys.path.insert(0, os.path.join(ROOT, 'qcc_amd', 'dropin'))
+  try:
+    xg = importlib.import_module('libxgates')
+  finally:
+    sys.path.pop(0)
+  rng = np.random.default_rng(2)
+  for bw, dt, tol in ((128, np.complex128, 1e-13), (64, np.complex64, 1e-6)):
+    n = 7
+    psi = (rng.standard_normal(1 << n) + 1j * rng.standard_normal(1 << n)).astype(dt)
+    want = psi.copy()
+    gate = (rng.standard_normal(4) + 1j * rng.standard_normal(4)).astype(dt)
+    assert xg.apply1(psi, gate, n, 2, bw) is None
+    oracle.apply1(want, gate, n, 2)
+    xg.applyc(psi, gate, n, 6, 0, bw)
+    oracle.applyc(want, gate, n, 6, 0)
+    assert np.max(np.abs(psi - want)) < tol * 10
+  with pytest.raises(TypeError):
+    xg.apply1(np.zeros(4, dtype=np.complex64), np.eye(2).reshape(4), 2, 0, 128)
+
+
+def test_measure_and_snapshots_on_gpu():
+  qc = circuit.qc('m')
+  qc.reg(5, 0b10110)
+  qc.h(0); qc.cx(0, 1); qc.ry(2, 0.7); qc.cu1(2, 3, 0.4); qc.h(4)
+  ref = qc.psi
+  for idx in range(5):
+    for to in (0, 1):
+      p_host, collapsed = ops.Measure(ref, idx, to, True) if ops.Measure(ref, idx, to, False)[0] > 1e-9 else (0, None)
+      if collapsed is None:
+        continue
+      qc.psi = ref
+      p, snap = qc.measure_bit(idx, to, True)
+      assert abs(p - p_host) < 1e-13 and np.allclose(snap, collapsed, atol=1e-13)
+  qc.psi = ref
+  qc.h(0)
+  assert qc.psi is not ref and not qc.psi.flags.writeable
+
+
+def test_large_register_never_touches_host():
+  """28 qubits: reg() + gates + device-side readers, no 2^n host array (the
+  reference materialises 2^n amplitudes per reg(): circuit.py:121-129)."""
+  qc = circuit.qc('big')
+  r = qc.reg(27, 0)
+  qc.reg(1, 1)
+  qc.h(0); qc.cx(0, 27 - 1); qc.x(5)
+  assert qc._host is None
+  bits, p = qc.maxprob()
+  assert abs(p - 0.5) < 1e-12 and bits[5] == 1 and bits[27] == 1
+  assert abs(qc.norm2() - 1) < 1e-12
+  want0 = [0] * 28
+  want0[5] = 1; want0[27] = 1
+  assert abs(qc.prob(*want0) - 0.5) < 1e-12
+  assert qc._host is None
+  qc.close()

@@ -1,0 +1,176 @@
+"""CPU tests of the host-side API mirror (qcc_amd.lib): gate streams, register
+bookkeeping, snapshot semantics, composite gates -- with the GPU replaced by an
+oracle-backed stand-in through the backend test seams (tests/fake_device.py)."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from qcc_amd.lib import backend, circuit, ops, state, tensor
+from tests import fake_device
+
+
+@pytest.fixture(autouse=True)
+def cpu_backend():
+  tensor.set_tensor_width(128)
+  backend.set_device_factory(fake_device.OracleDevice)
+  backend.set_host_executor(fake_device.OracleHostExecutor())
+  yield
+  backend.set_device_factory(None)
+  backend.set_host_executor(None)
+  tensor.set_tensor_width(None)
+
+
+def _trace_of(qc):
+  tr = qc._dev.trace
+  ops_ = np.array([(-(2 ** 31) if c is None else c, t) for c, t, _ in tr], dtype=np.int64)
+  gs = np.array([g for _, _, g in tr]).view(np.float64).reshape(-1, 8)
+  return ops_, gs
+
+
+def test_qft12_matches_reference_golden(golden_dir):
+  g = np.load(os.path.join(golden_dir, 'g1_qft12.npz'))
+  qc = circuit.qc('qft12')
+  reg = qc.reg(12, tuple(int(b) for b in g['bits']))
+  qc.qft(reg)
+  ops_, gs = _trace_of(qc)
+  assert np.array_equal(ops_, g['ops'].astype(np.int64))     # same native call stream
+  assert np.array_equal(gs, g['gates'])                      # same gate doubles
+  assert np.max(np.abs(qc.psi - g['final'])) < 1e-14
+
+
+def test_multi_control_and_friends_match_reference_trace(golden_dir):
+  g = np.load(os.path.join(golden_dir, 'g5_multi_control.npz'))
+  qc = circuit.qc('mc')
+  qc.reg(4, (1, 0, 1, 1))
+  aux = qc.reg(4, 0)
+  qc.h([0, 1, 2, 3])
+  qc.multi_control([0, [1], 2], 3, aux, ops.PauliX(), 'mc-x')
+  qc.multi_control([0, 1, [2], 3], 7, aux, ops.Hadamard(), 'mc-h')
+  qc.cswap(0, 1, 2)
+  qc.swap(0, 3)
+  qc.ccu1(0, 1, 2, 0.77)
+  qc.crx(1, 2, 0.3); qc.cry([0], 3, 0.4); qc.crz(3, 0, 0.5)
+  ops_, gs = _trace_of(qc)
+  assert np.array_equal(ops_, g['ops'].astype(np.int64))
+  assert np.max(np.abs(gs - g['gates'])) < 1e-15             # sqrtm closed form vs scipy
+  assert np.max(np.abs(qc.psi - g['final'])) < 1e-13
+
+
+def test_qft_inverse_qft_traces(golden_dir):
+  for n in (4, 7, 10):
+    g = np.load(os.path.join(golden_dir, f'g5_qft_iqft_n{n}.npz'))
+    qc = circuit.qc('qft')
+    reg = qc.reg(n, (0b1011001110 >> (10 - n)))
+    qc.qft(reg)
+    qc.inverse_qft(list(reg)[: n // 2])
+    assert np.array_equal(_trace_of(qc)[0], g['ops'].astype(np.int64))
+    assert np.max(np.abs(qc.psi - g['final'])) < 1e-14
+
+
+def test_state_apply_methods_and_negative_controls(golden_dir):
+  g = np.load(os.path.join(golden_dir, 'py_fallback.npz'))
+  psi = state.bitstring(1, 0, 1, 0, 1)
+  for (c, t), gate in zip(g['ops'], g['gates'].view(np.complex128).reshape(-1, 2, 2)):
+    if c == -(2 ** 31):
+      psi.apply1(ops.Operator(gate), int(t))
+    else:
+      psi.applyc(ops.Operator(gate), int(c), int(t))
+  assert np.max(np.abs(psi - g['final'])) < 1e-14
+
+
+def test_registers_stay_symbolic_until_needed():
+  qc = circuit.qc('lazy')
+  qc.reg(20, 5)
+  qc.reg(1, 1)
+  qc.bitstring(1, 0)
+  qc.zeros(3); qc.ones(2)
+  assert qc.nbits == 28 and qc._host is None and qc._dev is None   # nothing materialised
+  assert qc._basis == (((((5 << 1) | 1) << 2 | 0b10) << 3) << 2) | 0b11
+  qc2 = circuit.qc('small')
+  qc2.reg(3, 5)
+  assert np.array_equal(np.asarray(qc2.psi), np.asarray(state.bitstring(1, 0, 1)))
+
+
+def test_snapshot_semantics():
+  qc = circuit.qc('snap')
+  qc.reg(3, 0)
+  qc.h(0)
+  before = qc.psi
+  assert not before.flags.writeable
+  assert qc.psi is before                      # no new download without new gates
+  qc.x(2)
+  after = qc.psi
+  assert after is not before and abs(before[0]) > 0.7 and abs(after[1]) > 0.7
+  qc.psi = before                              # entanglement_swap.py:80-83 pattern
+  assert np.allclose(qc.psi, before)
+  qc.h(0)
+  assert np.allclose(np.abs(qc.psi[0]), 1.0)
+
+
+def test_measure_bit_matches_projector_formulation():
+  qc = circuit.qc('m')
+  qc.reg(4, 0)
+  qc.h(0); qc.cx(0, 1); qc.ry(2, 0.7); qc.cu1(2, 3, 0.4); qc.h(3)
+  ref = qc.psi
+  for idx in range(4):
+    for to in (0, 1):
+      p_host, collapsed_host = ops.Measure(ref, idx, to, True)
+      qc.psi = ref
+      p, snap = qc.measure_bit(idx, to, True)
+      assert abs(p - p_host) < 1e-14
+      assert np.allclose(snap, collapsed_host, atol=1e-14)
+  qc.psi = ref
+  assert abs(qc.pauli_expectation(0)) < 1e-14
+  bits, p = qc.maxprob()
+  hb, hp = ref.maxprob()
+  assert bits == hb and abs(p - hp) < 1e-15
+
+
+def test_ir_inverse_control_by_and_run():
+  main = circuit.qc('main')
+  main.reg(4, 0b0110)
+  start = main.psi
+  sub = main.sub('blk')
+  sub.h(0); sub.cu1(0, 1, 0.3); sub.rx(1, 0.2); sub.cx(1, 2)
+  assert not sub.eager and sub.ir.ngates == 4
+  main.qc(sub, offset=1)
+  main.qc(sub.inverse(), offset=1)
+  assert np.allclose(main.psi, start, atol=1e-14)
+  c = circuit.qc('c', eager=False)
+  c.h(1); c.cx(1, 2)
+  c.control_by(0)
+  names = [str(n) for n in c.ir.gates if n.is_gate()]
+  assert names[0] == 'ch(0, 1)' and len(names) == 6       # h -> ch ; cx -> 5-gate ccx
+  lazy = circuit.qc('lazy', eager=False)
+  lazy.reg(2, 0)
+  lazy.h(0); lazy.cx(0, 1)
+  assert lazy._dev is None
+  lazy.run()
+  assert np.allclose(np.abs(lazy.psi) ** 2, [0.5, 0, 0, 0.5])
+  assert 'Gates : 2' in lazy.stats()
+
+
+def test_operator_and_tensor_api():
+  x = ops.PauliX()
+  assert (ops.Hadamard() @ ops.Hadamard()).is_close(ops.Identity())
+  assert ops.Cnot(0, 1)(state.bitstring(1, 0)).is_close(state.bitstring(1, 1))
+  assert ops.Swap(0, 2)(state.bitstring(1, 0, 0)).is_close(state.bitstring(0, 0, 1))
+  assert ops.Toffoli(0, 1, 2)(state.bitstring(1, 1, 0)).is_close(state.bitstring(1, 1, 1))
+  assert ops.Cnot0(0, 1)(state.bitstring(0, 0)).is_close(state.bitstring(0, 1))
+  assert x(state.zeros(3), 1).is_close(state.bitstring(0, 1, 0))
+  assert ops.Rk(2).is_close(ops.Sgate()) and ops.U3(0, 0, 0).is_unitary()
+  assert (x * x).nbits == 2 and x.kpow(0).shape == ()
+  assert ops.Vgate().is_unitary() and ops.PauliZ().is_hermitian() and x.is_permutation()
+  assert state.plus(2).is_close([0.5] * 4) and abs(state.qubit(alpha=0.6)[1] - 0.8) < 1e-7
+  assert str(state.Reg(3, 5, 2)) == '|101>' and list(state.Reg(3, 5, 2)) == [2, 3, 4]
+
+
+def test_complex64_policy():
+  tensor.set_tensor_width(64)
+  qc = circuit.qc('w64')
+  qc.reg(3, 1)
+  qc.h(0); qc.cx(0, 2)
+  assert qc.psi.dtype == np.complex64 and qc._dev.bit_width == 64
+  assert np.allclose(np.abs(qc.psi) ** 2, [0, 0.5, 0, 0, 0.5, 0, 0, 0], atol=1e-6)

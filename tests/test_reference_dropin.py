@@ -1,0 +1,58 @@
+"""Drop-in evidence, runnable only where the reference is mounted (this build
+container): the reference's OWN unit tests and algorithms executed against
+  (a) qcc_amd.lib installed as ``src.lib`` (the API mirror), and
+  (b) the reference's unmodified src/lib with only ``libxgates`` replaced by
+      qcc_amd/dropin/libxgates.py (the literal two-function boundary).
+No GPU here, so gate execution is the oracle-backed stand-in (tests/fake_device.py);
+the same runner accepts `gpu` / `dropin-gpu` on a machine that has both."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = '/root/reference/src'
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason='reference not mounted')
+
+REF_TESTS = ['circuit_test', 'state_test', 'tensor_test', 'helper_test', 'measure_test',
+             'equalities_test', 'bell_test', 'ops_test']
+# (algorithm, seconds it needs on the CPU stand-in are small for all of these)
+ALGOS = ['arith_classic', 'arith_quantum', 'entanglement_swap', 'estimate_pi', 'hadamard_test',
+         'hhl_2x2', 'inversion_test', 'pauli_rep', 'qram', 'quantum_mean', 'state_prep',
+         'state_prep_mottonen', 'supremacy', 'counting', 'minimum_finding', 'teleportation',
+         'superdense', 'swap_test', 'phase_estimation']
+
+
+def _run(path, mode, env=None):
+  e = dict(os.environ, PYTHONPATH=ROOT, **(env or {}))
+  r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'ref_runner.py'), path, mode],
+                     capture_output=True, text=True, timeout=600, env=e)
+  assert r.returncode == 0, (path, mode, r.stdout[-800:], r.stderr[-1500:])
+  return r
+
+
+@pytest.mark.parametrize('name', REF_TESTS)
+def test_reference_unit_tests_on_api_mirror(name):
+  r = _run(os.path.join(REF, 'lib', name + '.py'), 'cpu')
+  assert 'OK' in r.stderr
+
+
+@pytest.mark.parametrize('name', ['circuit_test', 'state_test'])
+def test_reference_unit_tests_on_literal_libxgates_dropin(name):
+  r = _run(os.path.join(REF, 'lib', name + '.py'), 'dropin-cpu')
+  assert 'OK' in r.stderr
+
+
+@pytest.mark.parametrize('name', ALGOS)
+def test_reference_algorithms_on_api_mirror(name):
+  _run(os.path.join(REF, name + '.py'), 'cpu')
+
+
+@pytest.mark.parametrize('name', ['arith_quantum', 'supremacy', 'qram'])
+def test_reference_algorithms_on_literal_libxgates_dropin(name):
+  _run(os.path.join(REF, name + '.py'), 'dropin-cpu')
+
+
+def test_complex128_width_on_api_mirror():
+  _run(os.path.join(REF, 'lib', 'circuit_test.py'), 'cpu', env={'QCC_TENSOR_WIDTH': '128'})
