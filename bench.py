@@ -36,6 +36,7 @@ def parse():
   ap.add_argument('--qubits', type=int, default=0, help='default 30 + log2(gpus)')
   ap.add_argument('--fusion', type=int, default=-1, help='0 per-gate kernels, 1 fused sweeps (default)')
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--sharded', action='store_true', help='use the multi-GPU layer even with one rank (smoke)')
   ap.add_argument('--cpu-qubits', type=int, default=30)
   ap.add_argument('--cpu-gates', type=int, default=8, help='gates of the stream timed on the CPU')
   return ap.parse_args()
@@ -145,7 +146,7 @@ def main():
   fusion = args.fusion if args.fusion >= 0 else native.QH_FUSE_SWEEP
 
   dist = None
-  if world > 1:
+  if world > 1 or args.sharded:
     from qcc_amd import sharded
     eng = sharded.ShardedState(n, fusion=fusion, local_rank=local_rank)
     dist = eng.dist
@@ -182,7 +183,7 @@ def main():
 
   # parity guard inside the bench: closed form on sampled amplitudes after the
   # first full QFT is checked in tests; here we check the norm (cheap, device-side)
-  norm2 = eng.norm2_global() if world > 1 else eng.norm2()
+  norm2 = eng.norm2_global() if dist is not None else eng.norm2()
 
   out = None
   if rank == 0:
@@ -191,7 +192,7 @@ def main():
     value = ngates * steps * shard_units / wall
     launches = max(1, stats['kernels_launched'])
     # ---- roofline of the dominant kernel --------------------------------------
-    if world == 1:
+    if world == 1 and dist is None:
       if fusion == native.QH_FUSE_OFF:
         is_ctl = ops[:, 0] != workloads.NO_CTL
         ms_d, n_d, swept_d, alg_d = class_pass(eng, ops, g8, is_ctl, 1)
@@ -229,11 +230,14 @@ def main():
         'event_ms_per_step': ev_ms / steps, 'norm2': norm2,
         'roofline': roofline,
     }
+    if dist is not None:
+      out['exchanges_per_step'] = stats.get('exchanges', 0) / steps
+      out['xgmi_bytes_per_rank_per_step'] = stats.get('exchanged_bytes', 0) / steps
     if not args.no_cpu_baseline and world == 1:
       out['cpu_baseline'] = cpu_baseline(args, ops, g8)
       out['gpu_over_cpu'] = out['whole_state_gate_applies_per_s'] / out['cpu_baseline']['value']
     print(json.dumps(out))
-  if world > 1:
+  if dist is not None:
     eng.close()
     dist.destroy_process_group()
 

@@ -1,0 +1,266 @@
+"""ShardedState: one 2^n-amplitude state across P = 2^g GPUs of a node.
+
+One process per GPU (torch.distributed; backend "nccl" == RCCL over xGMI on
+ROCm).  Rank r holds the 2^(n-g) amplitudes whose g TOP physical index bits
+equal r, in its own HBM, behind its own engine handle.  Per gate:
+
+  * target local, controls local         -> local kernels, no communication;
+  * control on a shard bit               -> ranks whose bit is 0 skip the gate,
+                                            the others run it without that control;
+  * DIAGONAL gate touching shard bits    -> a phase that depends on the rank:
+                                            local diagonal gate / scalar, no
+                                            communication (all 630 CU1 of a
+                                            36-qubit QFT are in this class or local);
+  * dense gate whose TARGET is a shard bit -> the shard bit is swapped with the
+    top local bit: each rank exchanges the half of its shard whose top local bit
+    differs from its own shard bit with the partner rank r ^ 2^k (pairwise
+    send/recv, chunked through a staging buffer so no second copy of the shard is
+    ever needed), the logical->physical bit map is updated, and the gate -- and
+    every later gate on that qubit -- is local.  A 36-qubit QFT on 8 GPUs needs
+    exactly 3 such exchanges (the H gates on qubits 2, 1, 0).
+
+There is no collective on the data path other than that pairwise exchange;
+reductions (norm, arg-max) are 8-16 byte all-reduces.
+
+The local engine is qcc_amd.device.DeviceState attached to a torch CUDA tensor
+(so torch.distributed can address the same HBM).  Tests substitute a CPU engine
+and the gloo backend through `engine_factory` to exercise exactly this routing /
+exchange / bit-map code with world_size 2 and 4.
+"""
+import math
+import os
+
+import numpy as np
+
+NO_CTL = -(2 ** 31)
+
+
+def _is_diag(g4):
+  return g4[1] == 0 and g4[2] == 0
+
+
+def _hip_engine_factory(nloc, local_rank, fusion):
+  """(engine, flat float64 torch view of the shard) on cuda:local_rank."""
+  import torch
+  from qcc_amd import device
+  torch.cuda.set_device(local_rank)
+  buf = torch.zeros(2 << nloc, dtype=torch.float64, device=f'cuda:{local_rank}')
+  eng = device.DeviceState(nloc, 128, device=local_rank, fusion=fusion, device_ptr=buf.data_ptr())
+  return eng, buf
+
+
+class ShardedState:
+  """complex128 state sharded by its top log2(P) physical index bits."""
+
+  def __init__(self, nbits, fusion=1, local_rank=None, *, engine_factory=None, backend=None,
+               chunk_amps=1 << 24):
+    import torch
+    import torch.distributed as dist
+    self.torch, self.dist = torch, dist
+    if not dist.is_initialized():
+      backend = backend or ('nccl' if torch.cuda.is_available() else 'gloo')
+      os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+      kw = {}
+      if backend == 'nccl' and local_rank is not None:
+        torch.cuda.set_device(local_rank)
+        try:
+          kw['device_id'] = torch.device(f'cuda:{local_rank}')
+        except Exception:  # pylint: disable=broad-except
+          kw = {}
+      dist.init_process_group(backend=backend, **kw)
+    self.rank, self.world = dist.get_rank(), dist.get_world_size()
+    self.g = int(math.log2(self.world))
+    assert 1 << self.g == self.world, 'number of ranks must be a power of two'
+    self.nbits = int(nbits)
+    self.nloc = self.nbits - self.g
+    assert self.nloc >= 2, 'shard too small'
+    local_rank = int(os.environ.get('LOCAL_RANK', '0')) if local_rank is None else local_rank
+    factory = engine_factory or (lambda nloc: _hip_engine_factory(nloc, local_rank, fusion))
+    self.eng, self.buf = factory(self.nloc)
+    # logical bit b (0 = least significant; qubit q is bit nbits-1-q) -> physical bit
+    self.perm = list(range(self.nbits))
+    self.chunk = min(int(chunk_amps), 1 << (self.nloc - 1))
+    self._staging = None
+    self.exchanges = 0
+    self.exchanged_bytes = 0
+    self.gates = 0
+
+  # ------------------------------------------------------------------ helpers
+  def _phys_mask(self, logical_mask):
+    m, b = 0, 0
+    while logical_mask:
+      if logical_mask & 1:
+        m |= 1 << self.perm[b]
+      logical_mask >>= 1
+      b += 1
+    return m
+
+  def logical_to_phys(self, idx):
+    return self._phys_mask(idx)
+
+  def phys_to_logical(self, idx):
+    out = 0
+    for b in range(self.nbits):
+      if (idx >> self.perm[b]) & 1:
+        out |= 1 << b
+    return out
+
+  def init_basis(self, index):
+    """|index> (logical); only the owning rank gets the 1."""
+    phys = self.logical_to_phys(int(index))
+    self.eng.sync()
+    self.buf.zero_()
+    if self.buf.is_cuda:
+      self.torch.cuda.synchronize()
+    if (phys >> self.nloc) == self.rank:
+      self.buf[2 * (phys & ((1 << self.nloc) - 1))] = 1.0
+    if self.buf.is_cuda:
+      self.torch.cuda.synchronize()
+
+  # ------------------------------------------------------------------ gates
+  def apply_bits(self, ctl_mask, tgt_bit, gate):
+    """Gate on LOGICAL bit tgt_bit under logical control mask (all ranks call this)."""
+    g4 = np.asarray(gate, dtype=np.complex128).reshape(4)
+    self.gates += 1
+    pt = self.perm[tgt_bit]
+    diag = _is_diag(g4)
+    if pt >= self.nloc and not diag:
+      self._exchange(pt)                      # collective: before any rank-dependent skip
+      pt = self.perm[tgt_bit]
+    pm = self._phys_mask(ctl_mask)
+    hi = pm >> self.nloc
+    if (self.rank & hi) != hi:
+      return                                   # a control lives in the rank index and is 0 here
+    cm = pm & ((1 << self.nloc) - 1)
+    if pt >= self.nloc:                        # diagonal on a shard bit: rank-dependent factor
+      f = g4[3] if (self.rank >> (pt - self.nloc)) & 1 else g4[0]
+      if f == 1:
+        return
+      if cm:
+        c = (cm & -cm).bit_length() - 1
+        self.eng.apply_bits(cm & ~(1 << c), c, np.array([1, 0, 0, f], dtype=np.complex128))
+      else:
+        self.eng.apply_bits(0, 0, np.array([f, 0, 0, f], dtype=np.complex128))
+      return
+    self.eng.apply_bits(cm, pt, g4)
+
+  def apply1(self, gate, index):
+    self.apply_bits(0, self.nbits - 1 - int(index), gate)
+
+  def applyc(self, gate, control, target):
+    c = self.nbits - 1 - int(control)
+    if not 0 <= c < self.nbits:
+      raise ValueError(f'control qubit {control} out of range')
+    self.apply_bits(1 << c, self.nbits - 1 - int(target), gate)
+
+  def run_stream(self, ops, gates8):
+    gc = np.ascontiguousarray(gates8, dtype=np.float64).view(np.complex128).reshape(-1, 4)
+    for k in range(len(ops)):
+      c, t = int(ops[k, 0]), int(ops[k, 1])
+      if c == NO_CTL:
+        self.apply1(gc[k], t)
+      else:
+        self.applyc(gc[k], c, t)
+
+  # ------------------------------------------------------------------ the exchange step
+  def _exchange(self, shard_phys_bit):
+    """Swap the data of physical shard bit with the top local bit (pairwise, in place)."""
+    torch, dist = self.torch, self.dist
+    k = shard_phys_bit - self.nloc
+    top = self.nloc - 1
+    partner = self.rank ^ (1 << k)
+    mybit = (self.rank >> k) & 1
+    half = 1 << top                                   # amplitudes
+    start = (1 - mybit) * half                        # the half whose top bit != my shard bit
+    self.eng.sync()                                   # kernels done before RCCL touches the shard
+    if self._staging is None:
+      self._staging = torch.empty(2 * self.chunk, dtype=self.buf.dtype, device=self.buf.device)
+    for off in range(0, half, self.chunk):
+      n = min(self.chunk, half - off)
+      view = self.buf[2 * (start + off): 2 * (start + off + n)]
+      stage = self._staging[: 2 * n]
+      reqs = dist.batch_isend_irecv([dist.P2POp(dist.isend, view, partner),
+                                     dist.P2POp(dist.irecv, stage, partner)])
+      for r in reqs:
+        r.wait()
+      view.copy_(stage)
+    if self.buf.is_cuda:
+      torch.cuda.synchronize()
+    # bookkeeping: the two logical bits trade physical homes
+    la = self.perm.index(shard_phys_bit)
+    lb = self.perm.index(top)
+    self.perm[la], self.perm[lb] = top, shard_phys_bit
+    self.exchanges += 1
+    self.exchanged_bytes += half * 16
+
+  # ------------------------------------------------------------------ readers
+  def flush(self):
+    self.eng.flush()
+
+  def sync(self):
+    self.eng.sync()
+
+  def norm2_global(self):
+    t = self.torch.tensor([self.eng.norm2()], dtype=self.torch.float64, device=self.buf.device)
+    self.dist.all_reduce(t)
+    return float(t.item())
+
+  def argmax_global(self):
+    """(logical index, probability) of the likeliest basis state."""
+    li, p = self.eng.argmax()
+    phys = (self.rank << self.nloc) | li
+    t = self.torch.tensor([p, float(self.rank)], dtype=self.torch.float64, device=self.buf.device)
+    allp = [self.torch.zeros_like(t) for _ in range(self.world)]
+    self.dist.all_gather(allp, t)
+    idx = self.torch.tensor([phys], dtype=self.torch.int64, device=self.buf.device)
+    alli = [self.torch.zeros_like(idx) for _ in range(self.world)]
+    self.dist.all_gather(alli, idx)
+    best = max(range(self.world), key=lambda r: (float(allp[r][0]), -r))
+    return self.phys_to_logical(int(alli[best].item())), float(allp[best][0])
+
+  def amplitude_local(self, logical_index):
+    """Amplitude if this rank owns it, else None."""
+    phys = self.logical_to_phys(int(logical_index))
+    if (phys >> self.nloc) != self.rank:
+      return None
+    return self.eng.amplitude(phys & ((1 << self.nloc) - 1))
+
+  def gather_logical(self):
+    """Whole state in LOGICAL order on every rank (tests / small n only)."""
+    torch = self.torch
+    self.eng.sync()
+    mine = self.buf.detach().to('cpu') if self.buf.is_cuda else self.buf
+    parts = [torch.zeros_like(mine) for _ in range(self.world)]
+    if self.buf.is_cuda:
+      cu = [torch.zeros_like(self.buf) for _ in range(self.world)]
+      self.dist.all_gather(cu, self.buf)
+      parts = [c.cpu() for c in cu]
+    else:
+      self.dist.all_gather(parts, mine)
+    phys = np.concatenate([p.numpy().view(np.complex128) for p in parts])
+    idx = np.arange(1 << self.nbits, dtype=np.uint64)
+    pidx = np.zeros_like(idx)
+    for b in range(self.nbits):
+      pidx |= ((idx >> np.uint64(b)) & np.uint64(1)) << np.uint64(self.perm[b])
+    return phys[pidx]
+
+  def timer_begin(self):
+    self.eng.timer_begin()
+
+  def timer_end(self):
+    return self.eng.timer_end()
+
+  def stats(self):
+    s = self.eng.stats()
+    s['exchanges'] = self.exchanges
+    s['exchanged_bytes'] = self.exchanged_bytes
+    return s
+
+  def reset_stats(self):
+    self.eng.reset_stats()
+    self.exchanges = 0
+    self.exchanged_bytes = 0
+
+  def close(self):
+    self.eng.sync()
+    self.eng.close()

@@ -82,3 +82,51 @@ class OracleHostExecutor:
 
   def applyc(self, psi, gate, nbits, ctl, tgt, bit_width=128):
     self.o.applyc(psi, gate, nbits, ctl, tgt)
+
+
+class NumpyShardEngine:
+  """CPU stand-in for the per-rank engine of qcc_amd.sharded.ShardedState: local
+  physical bits only, state shared with a torch CPU tensor so gloo can move it."""
+
+  def __init__(self, nloc):
+    import torch
+    self.nbits = nloc
+    self.psi = np.zeros(1 << nloc, dtype=np.complex128)
+    self.buf = torch.from_numpy(self.psi.view(np.float64))
+    self.n_gates = 0
+
+  def apply_bits(self, ctl_mask, tgt_bit, gate):
+    g = np.asarray(gate, dtype=np.complex128).reshape(2, 2)
+    idx = np.arange(self.psi.size)
+    sel = ((idx & ctl_mask) == ctl_mask) & (((idx >> tgt_bit) & 1) == 0)
+    lo = idx[sel]
+    hi = lo | (1 << tgt_bit)
+    a, b = self.psi[lo].copy(), self.psi[hi].copy()
+    self.psi[lo] = g[0, 0] * a + g[0, 1] * b
+    self.psi[hi] = g[1, 0] * a + g[1, 1] * b
+    self.n_gates += 1
+
+  def sync(self):
+    pass
+
+  def flush(self):
+    pass
+
+  def close(self):
+    pass
+
+  def norm2(self):
+    return float(np.vdot(self.psi, self.psi).real)
+
+  def argmax(self):
+    i = int(np.argmax(np.abs(self.psi)))
+    return i, float(np.abs(self.psi[i]) ** 2)
+
+  def amplitude(self, i):
+    return self.psi[i]
+
+  def stats(self):
+    return {'gates_submitted': self.n_gates}
+
+  def reset_stats(self):
+    self.n_gates = 0
