@@ -135,6 +135,8 @@ def main():
   if world != args.gpus:
     if world == 1 and args.gpus > 1:
       raise SystemExit('bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)')
+  if world > 1 or args.sharded:
+    os.environ['QCC_PRELOAD_TORCH'] = '1'  # one HIP runtime per process: torch's (qcc_amd/native.py)
   from qcc_amd import device, native, workloads
   if native.device_count() < 1:
     raise SystemExit('bench.py: no HIP device visible; the engine has no CPU fallback')

@@ -98,11 +98,26 @@ def build(force=False, verbose=False):
 _lib = None
 
 
+def _preload_torch_runtime():
+  """One process must hold ONE HIP runtime.  The PyTorch-ROCm wheel bundles its own
+  libamdhip64.so; if ours (/opt/rocm) is mapped first, torch afterwards sees no
+  GPU (measured on the MI355X box: tools/order_probe.py).  Whenever this process
+  is going to use torch.distributed (multi-GPU runs launched by torchrun set
+  WORLD_SIZE), import torch BEFORE dlopen()ing the engine so that the engine's
+  DT_NEEDED libamdhip64.so.7 resolves to the copy torch already mapped."""
+  import sys
+  if 'torch' in sys.modules:
+    return
+  if os.environ.get('WORLD_SIZE') or os.environ.get('QCC_PRELOAD_TORCH') == '1':
+    import torch  # noqa: F401  pylint: disable=import-outside-toplevel,unused-import
+
+
 def load():
   """Load libqcc_hip.so and bind every declared symbol.  No fallback."""
   global _lib
   if _lib is not None:
     return _lib
+  _preload_torch_runtime()
   if not os.path.exists(LIB_PATH):
     raise RuntimeError(
         f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '

@@ -43,6 +43,10 @@ def _hip_engine_factory(nloc, local_rank, fusion):
   """(engine, flat float64 torch view of the shard) on cuda:local_rank."""
   import torch
   from qcc_amd import device
+  if not torch.cuda.is_available():
+    raise RuntimeError('torch sees no GPU.  If the engine library was loaded before torch was imported, two HIP '
+                       'runtimes are mapped (see qcc_amd.native._preload_torch_runtime): import torch first or '
+                       'launch through torchrun / set QCC_PRELOAD_TORCH=1')
   torch.cuda.set_device(local_rank)
   buf = torch.zeros(2 << nloc, dtype=torch.float64, device=f'cuda:{local_rank}')
   eng = device.DeviceState(nloc, 128, device=local_rank, fusion=fusion, device_ptr=buf.data_ptr())
