@@ -103,6 +103,12 @@ class DeviceState:
     _keep, p = _g8(gate)
     native.check(self.lib.qh_apply_bits(self.h, int(ctl_mask), int(tgt_bit), p))
 
+  def apply_bits_raw(self, ctl_mask, tgt_bit, addr):
+    """apply_bits with the gate given as the address of 8 contiguous doubles."""
+    rc = self.lib.qh_apply_bits(self.h, ctl_mask, tgt_bit, ctypes.cast(addr, _dp))
+    if rc:
+      native.check(rc)
+
   def run_stream(self, ops, gates8):
     """ops int32[G,2] (ctl or NO_CTL, tgt), gates8 float64[G,8] -- reference qubit numbers."""
     ops = np.ascontiguousarray(ops, dtype=np.int32)

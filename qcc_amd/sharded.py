@@ -158,13 +158,50 @@ class ShardedState:
     self.apply_bits(1 << c, self.nbits - 1 - int(target), gate)
 
   def run_stream(self, ops, gates8):
-    gc = np.ascontiguousarray(gates8, dtype=np.float64).view(np.complex128).reshape(-1, 4)
-    for k in range(len(ops)):
-      c, t = int(ops[k, 0]), int(ops[k, 1])
-      if c == NO_CTL:
-        self.apply1(gc[k], t)
+    """Replay (ops int32[G,2], gates float64[G,8]) in reference qubit numbers.
+
+    Same routing as apply_bits, with the per-gate Python work reduced to a few
+    integer operations (the common case -- local target, at most one control --
+    goes straight to qh_apply_bits with a pointer into `gates8`)."""
+    ops = np.ascontiguousarray(ops, dtype=np.int32)
+    g8 = np.ascontiguousarray(gates8, dtype=np.float64)
+    n, nloc, rank = self.nbits, self.nloc, self.rank
+    diag = ((g8[:, 2:6] == 0).all(axis=1)).tolist()
+    tbits = (n - 1 - ops[:, 1]).tolist()
+    cq = ops[:, 0].tolist()
+    base = g8.ctypes.data
+    raw = self.eng.apply_bits_raw
+    perm = self.perm
+    gc = None
+    for k in range(len(cq)):
+      tb = tbits[k]
+      pt = perm[tb]
+      if pt >= nloc:
+        if not diag[k]:
+          self._exchange(pt)
+          perm = self.perm
+          pt = perm[tb]
+        else:                                  # diagonal on a shard bit: general path
+          if gc is None:
+            gc = g8.view(np.complex128).reshape(-1, 4)
+          cmask = 0 if cq[k] == NO_CTL else 1 << (n - 1 - cq[k])
+          self.apply_bits(cmask, tb, gc[k])
+          continue
+      if cq[k] == NO_CTL:
+        cm = 0
       else:
-        self.applyc(gc[k], c, t)
+        c = n - 1 - cq[k]
+        if not 0 <= c < n:
+          raise ValueError(f'control qubit {cq[k]} out of range')
+        pc = perm[c]
+        if pc >= nloc:
+          if not (rank >> (pc - nloc)) & 1:
+            continue
+          cm = 0
+        else:
+          cm = 1 << pc
+      raw(cm, pt, base + 64 * k)
+    self.gates += len(cq)
 
   # ------------------------------------------------------------------ the exchange step
   def _exchange(self, shard_phys_bit):

@@ -106,6 +106,11 @@ class NumpyShardEngine:
     self.psi[hi] = g[1, 0] * a + g[1, 1] * b
     self.n_gates += 1
 
+  def apply_bits_raw(self, ctl_mask, tgt_bit, addr):
+    import ctypes
+    g = np.ctypeslib.as_array(ctypes.cast(addr, ctypes.POINTER(ctypes.c_double)), shape=(8,)).copy()
+    self.apply_bits(ctl_mask, tgt_bit, g.view(np.complex128))
+
   def sync(self):
     pass
 

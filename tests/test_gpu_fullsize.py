@@ -1,0 +1,77 @@
+"""BASELINE.json configs 3 and 4 at full size on one MI355X.
+
+The reference cannot run these sizes (32-bit indices stop at 30 qubits and a
+30-qubit gate takes seconds on its single thread), so parity rests on
+size-independent properties plus the chain of trust
+GPU == oracle == reference established at <= 22 qubits:
+  * two independent GPU implementations (per-gate kernels vs fused sweeps) agree
+    amplitude by amplitude on sampled windows;
+  * circuit followed by its inverse returns the basis state; norm stays 1;
+  * closed forms: the Grover 4-amplitude recurrence."""
+import math
+
+import numpy as np
+import pytest
+
+from qcc_amd import device, native, workloads
+
+pytestmark = pytest.mark.gpu
+
+
+def _inverse(ops, g8):
+  inv_ops = ops[::-1].copy()
+  c = g8[::-1].copy().reshape(-1, 4, 2)
+  z = (c[..., 0] + 1j * c[..., 1]).reshape(-1, 2, 2)
+  zi = np.conj(z.transpose(0, 2, 1)).reshape(-1, 4)
+  return inv_ops, np.ascontiguousarray(zi).view(np.float64).reshape(-1, 8)
+
+
+def test_config3_supremacy_30q_depth20():
+  n = 30
+  ops, g8 = workloads.supremacy_stream(n, 20, seed=0).arrays()
+  assert len(ops) == 342                      # 30 H, 117 V/Yroot, 80 T, 115 CZ
+  rng = np.random.default_rng(3)
+  offs = [int(o) for o in rng.integers(0, (1 << n) - 4096, size=6)] + [0, (1 << n) - 4096]
+  windows = {}
+  for fusion in (native.QH_FUSE_SWEEP, native.QH_FUSE_OFF):
+    with device.DeviceState(n, 128, fusion=fusion) as st:
+      st.init_basis(0)
+      st.run_stream(ops, g8)
+      assert abs(st.norm2() - 1.0) < 1e-10
+      windows[fusion] = np.concatenate([st.download(o, 4096) for o in offs])
+      if fusion == native.QH_FUSE_SWEEP:
+        st.run_stream(*_inverse(ops, g8))
+        i, p = st.argmax()
+        assert i == 0 and abs(p - 1.0) < 1e-9
+  a, b = windows[native.QH_FUSE_SWEEP], windows[native.QH_FUSE_OFF]
+  assert np.max(np.abs(a)) > 1e-6             # a dense, non-trivial state
+  assert np.max(np.abs(a - b)) <= 1e-10
+
+
+def test_config4_grover_34q_one_iteration():
+  nb = 17
+  n = 2 * nb
+  marked = [1, 0] * 8 + [1]
+  ops, g8 = workloads.grover_stream(nb, marked, iterations=1).arrays()
+  try:
+    st = device.DeviceState(n, 128, fusion=native.QH_FUSE_SWEEP)
+  except native.QhError as e:
+    if e.code == native.QH_ERR_NOMEM:
+      pytest.skip(f'cannot allocate the 256 GiB state on this box: {e}')
+    raise
+  with st:
+    st.init_basis(workloads.grover_initial_index(nb))
+    st.run_stream(ops, g8)
+    assert abs(st.norm2() - 1.0) < 1e-9
+    cm0, cm1, cu0, cu1 = workloads.grover_recurrence(nb, 1)
+    x = int(''.join(map(str, marked)), 2)
+    anc = 1 << (nb - 1)
+    rng = np.random.default_rng(4)
+    others = [int(v) for v in rng.integers(0, 1 << nb, size=8) if int(v) != x]
+    for xx, (c0, c1) in [(x, (cm0, cm1))] + [(o, (cu0, cu1)) for o in others]:
+      assert abs(st.amplitude((xx << nb) | 0) - c0) < 1e-12
+      assert abs(st.amplitude((xx << nb) | anc) - c1) < 1e-12
+      assert abs(st.amplitude((xx << nb) | 1)) < 1e-14        # aux != 0 stays empty
+      assert abs(st.amplitude((xx << nb) | anc | 5)) < 1e-14
+    s = st.stats()
+    assert s['gates_submitted'] == len(ops)

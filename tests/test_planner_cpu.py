@@ -1,0 +1,101 @@
+"""CPU tests of the sweep planner (qcc_amd/csrc/planner.h) through the C-ABI's
+dry handle + qh_plan_json: no GPU needed to check what would be launched."""
+import ctypes
+import json
+
+import numpy as np
+import pytest
+
+from qcc_amd import gates, native, workloads
+
+_dp = ctypes.POINTER(ctypes.c_double)
+
+
+def _plan(n, ops, g8, shard=None):
+  lib = native.load()
+  h = ctypes.c_void_p()
+  native.check(lib.qh_create_dry(n if shard is None else shard[0], 128, ctypes.byref(h)))
+  if shard is not None:
+    native.check(lib.qh_set_shard(h, n, shard[1]))
+  native.check(lib.qh_set_fusion(h, native.QH_FUSE_SWEEP))
+  g8 = np.ascontiguousarray(g8, dtype=np.float64)
+  for k in range(len(ops)):
+    gp = ctypes.cast(g8.ctypes.data + 64 * k, _dp)
+    c, t = int(ops[k, 0]), int(ops[k, 1])
+    native.check(lib.qh_apply1(h, t, gp) if c == workloads.NO_CTL else lib.qh_applyc(h, c, t, gp))
+  need = ctypes.c_uint64()
+  lib.qh_plan_json(h, None, 0, ctypes.byref(need))
+  buf = ctypes.create_string_buffer(need.value)
+  lib.qh_plan_json(h, buf, need.value, None)
+  lib.qh_destroy(h)
+  return json.loads(buf.value.decode())
+
+
+def test_qft30_is_five_sweeps_and_accounts_every_gate():
+  n = 30
+  ops, g8 = workloads.qft_stream(range(n)).arrays()
+  p = _plan(n, ops, g8)
+  sw = p['sweeps']
+  S = 16 * 2 ** n
+  assert len(sw) == 5
+  assert sum(s['gates'] for s in sw) + p['noop_gates'] == 465
+  assert sw[0]['regpos'] == [6, 7, 8, 9, 10] and sw[0]['dense_ops'] == 11
+  assert all(s['swept_bytes'] == 2 * S for s in sw)            # one read + one write each
+  # minimal-touch bytes of BASELINE.md: 30 H x 2S + 435 CU1 x S/2 = 277.5 S
+  assert sum(s['alg_bytes'] for s in sw) == int(277.5 * S)
+  # lazy diagonal placement + tables: no per-gate loop terms left in the big sweep
+  assert sw[0]['oterms'] == 0 and sw[0]['groups'] <= 40
+
+
+def test_lone_controlled_phase_moves_only_touched_amplitudes():
+  n = 24
+  sb = workloads.StreamBuilder()
+  sb.applyc(gates.u1(0.3), 2, 5)            # bits 21 and 18: both above the lane bits
+  p = _plan(n, *sb.arrays())
+  (s,) = p['sweeps']
+  assert s['fixed_ones'] == (1 << 21) | (1 << 18)
+  assert s['swept_bytes'] == s['alg_bytes'] == 16 * 2 ** n // 2   # S/2, not 2S
+  sb = workloads.StreamBuilder()
+  sb.apply1(gates.tgate(), 3)
+  (s,) = _plan(n, *sb.arrays())['sweeps']
+  assert s['swept_bytes'] == 16 * 2 ** n                          # S
+
+
+def test_commutation_rules_keep_order_where_it_matters():
+  """H(a) X(b) H(a): the second H(a) may not overtake ... and a gate skipped for
+  lack of register bits blocks later gates on its bits."""
+  n = 20
+  sb = workloads.StreamBuilder()
+  for q in range(7):                       # 7 distinct high targets: only 5 fit one sweep
+    sb.apply1(gates.hadamard(), q)
+  sb.applyc(gates.pauli_x(), 5, 0)         # dense on qubit 0, control on skipped qubit 5
+  sb.apply1(gates.hadamard(), 5)
+  p = _plan(n, *sb.arrays())
+  assert len(p['sweeps']) == 2
+  assert p['sweeps'][0]['gates'] == 5      # H(q0..q4); H(q5), H(q6) wait
+  # CX(5->0) must come after H(5)?? no: after the skipped H(q5) -- it shares qubit 5 with it
+  assert p['sweeps'][1]['gates'] == 4
+
+
+def test_shard_bit_predicates_resolved_at_plan_time():
+  n, nloc = 12, 10
+  sb = workloads.StreamBuilder()
+  sb.applyc(gates.hadamard(), 0, 5)        # control = shard bit 1
+  sb.applyc(gates.u1(0.5), 5, 1)           # diagonal target = shard bit 0
+  sb.apply1(gates.rz(0.2), 0)              # diagonal on shard bit 1
+  ops, g8 = sb.arrays()
+  for shard in range(4):
+    p = _plan(n, ops, g8, shard=(nloc, shard))
+    gates_run = sum(s['gates'] for s in p['sweeps'])
+    want = (1 if shard & 2 else 0) + (1 if shard & 1 else 0) + 1
+    assert gates_run == want and gates_run + p['noop_gates'] == 3
+
+
+def test_supremacy_and_grover_streams_plan_completely():
+  ops, g8 = workloads.supremacy_stream(30, 20, seed=0).arrays()
+  p = _plan(30, ops, g8)
+  assert sum(s['gates'] for s in p['sweeps']) + p['noop_gates'] == len(ops) == 342
+  assert len(p['sweeps']) <= 16
+  ops, g8 = workloads.grover_stream(10, [1, 0] * 5, iterations=1).arrays()
+  p = _plan(20, ops, g8)
+  assert sum(s['gates'] for s in p['sweeps']) + p['noop_gates'] == len(ops)
