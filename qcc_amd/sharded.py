@@ -57,7 +57,7 @@ class ShardedState:
   """complex128 state sharded by its top log2(P) physical index bits."""
 
   def __init__(self, nbits, fusion=1, local_rank=None, *, engine_factory=None, backend=None,
-               chunk_amps=1 << 24):
+               chunk_amps=1 << 24, exchange='alltoall'):
     import torch
     import torch.distributed as dist
     self.torch, self.dist = torch, dist
@@ -84,6 +84,8 @@ class ShardedState:
     # logical bit b (0 = least significant; qubit q is bit nbits-1-q) -> physical bit
     self.perm = list(range(self.nbits))
     self.chunk = min(int(chunk_amps), 1 << (self.nloc - 1))
+    assert exchange in ('alltoall', 'pairwise')
+    self.exchange_mode = exchange if self.nloc >= 2 * self.g else 'pairwise'
     self._staging = None
     self.exchanges = 0
     self.exchanged_bytes = 0
@@ -205,6 +207,52 @@ class ShardedState:
 
   # ------------------------------------------------------------------ the exchange step
   def _exchange(self, shard_phys_bit):
+    if self.exchange_mode == 'alltoall' and self.g > 1:
+      self._exchange_all()
+    else:
+      self._exchange_pair(shard_phys_bit)
+
+  def _exchange_all(self):
+    """Swap ALL g shard bits with the top g local bits in one step.
+
+    The shard is P blocks (selected by its top g local bits); block j goes to
+    rank j and lands there as block `rank`; block `rank` stays.  Every rank talks
+    to its P-1 peers at once (one grouped send/recv per peer and chunk), so all
+    xGMI links of the GPU carry 1/P of the shard each -- instead of g successive
+    pairwise exchanges of half a shard over a single link.  In place: chunks go
+    through a (P-1) x chunk staging buffer."""
+    torch, dist = self.torch, self.dist
+    P, g, r = self.world, self.g, self.rank
+    blk = 1 << (self.nloc - g)                       # amplitudes per block
+    chunk = min(self.chunk, blk)
+    self.eng.sync()
+    need = 2 * chunk * (P - 1)
+    if self._staging is None or self._staging.numel() < need:
+      self._staging = torch.empty(need, dtype=self.buf.dtype, device=self.buf.device)
+    peers = [j for j in range(P) if j != r]
+    for off in range(0, blk, chunk):
+      n = min(chunk, blk - off)
+      ops, pairs = [], []
+      for slot, j in enumerate(peers):
+        view = self.buf[2 * (j * blk + off): 2 * (j * blk + off + n)]
+        stage = self._staging[2 * chunk * slot: 2 * chunk * slot + 2 * n]
+        ops.append(dist.P2POp(dist.isend, view, j))
+        ops.append(dist.P2POp(dist.irecv, stage, j))
+        pairs.append((view, stage))
+      for req in dist.batch_isend_irecv(ops):
+        req.wait()
+      for view, stage in pairs:
+        view.copy_(stage)
+    if self.buf.is_cuda:
+      torch.cuda.synchronize()
+    for k in range(g):                               # shard bit k <-> local bit nloc-g+k
+      a_phys, b_phys = self.nloc + k, self.nloc - g + k
+      la, lb = self.perm.index(a_phys), self.perm.index(b_phys)
+      self.perm[la], self.perm[lb] = b_phys, a_phys
+    self.exchanges += 1
+    self.exchanged_bytes += (P - 1) * blk * 16
+
+  def _exchange_pair(self, shard_phys_bit):
     """Swap the data of physical shard bit with the top local bit (pairwise, in place)."""
     torch, dist = self.torch, self.dist
     k = shard_phys_bit - self.nloc

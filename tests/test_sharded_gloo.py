@@ -43,7 +43,7 @@ def _stream(n, seed):
   return ops, g8
 
 
-def _worker(rank, world, port, n, seed, out_dir):
+def _worker(rank, world, port, n, seed, out_dir, mode='alltoall'):
   os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                     LOCAL_RANK=str(rank))
   import torch.distributed as dist
@@ -54,7 +54,7 @@ def _worker(rank, world, port, n, seed, out_dir):
   def factory(nloc):
     e = fake_device.NumpyShardEngine(nloc)
     return e, e.buf
-  st = sharded.ShardedState(n, engine_factory=factory, chunk_amps=8)   # tiny chunks: many rounds
+  st = sharded.ShardedState(n, engine_factory=factory, chunk_amps=8, exchange=mode)   # tiny chunks: many rounds
   ops, g8 = _stream(n, seed)
   x = 0b1011010 & ((1 << n) - 1)
   st.init_basis(x)
@@ -69,10 +69,11 @@ def _worker(rank, world, port, n, seed, out_dir):
   dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world,n,seed', [(2, 6, 0), (4, 7, 1), (2, 8, 2)])
-def test_sharded_equals_single_process_oracle(oracle, tmp_path, world, n, seed):
+@pytest.mark.parametrize('world,n,seed,mode', [(2, 6, 0, 'alltoall'), (4, 7, 1, 'alltoall'), (4, 8, 2, 'pairwise'),
+                                               (4, 9, 3, 'alltoall')])
+def test_sharded_equals_single_process_oracle(oracle, tmp_path, world, n, seed, mode):
   port = _free_port()
-  mp.spawn(_worker, args=(world, port, n, seed, str(tmp_path)), nprocs=world, join=True)
+  mp.spawn(_worker, args=(world, port, n, seed, str(tmp_path), mode), nprocs=world, join=True)
   res = np.load(tmp_path / 'res.npz')
   ops, g8 = _stream(n, seed)
   want = np.zeros(1 << n, dtype=np.complex128)
@@ -92,7 +93,7 @@ def test_qft_needs_exactly_g_exchanges(tmp_path):
   port = _free_port()
   mp.spawn(_qft_only, args=(world, port, n, str(tmp_path)), nprocs=world, join=True)
   res = np.load(tmp_path / 'qft.npz')
-  assert int(res['exchanges']) == 2
+  assert int(res['exchanges']) == 1                      # one all-to-all instead of g=2 pairwise steps
   k = np.arange(1 << n)
   want = workloads.qft_analytic(n, 0b0110101, k)
   assert np.max(np.abs(res['psi'] - want)) < 1e-12

@@ -10,26 +10,29 @@ VGPRs, spills at RB=5, one v_mov per amplitude per op), so the loop is written
 by hand: every op updates the tile in place.
 
 Register map (island-private, declared as clobbers to the compiler):
-  v[64+4k .. 64+4k+3]   tile slot k: x = v[+0:+1], y = v[+2:+3]
-  v16..v63              temporaries (see names below)
-  s36..s99              scalar state (op header, gate matrix, cursors, masks)
+  v[T0+4k .. T0+4k+3]   tile slot k: x = v[+0:+1], y = v[+2:+3]; T0 = 40
+  v16..v39              24 temporaries, reused per op kind (see V below)
+                        => 168 VGPRs at RB=5: THREE waves per SIMD
+  s36..s99              scalar state (op header, gate matrix / group header,
+                        cursors, masks, table entries)
 Operands supplied by the C++ kernel:
   %0,%1  tile base address lo,hi (SGPR)      %2  SweepParams* (SGPR pair)
   %3     tile index (idx_high|base) (SGPR pair, for outside-bit predicates)
   %4     lane*16 (VGPR)  %5 lane (VGPR)  %6,%7 thread index lo,hi (VGPR)
-Data layouts must match planner.h (SweepOp 96 B, DGroup 32 B, OTerm 24 B) and
+Data layouts must match planner.h (SweepOp 96 B, DGroup 64 B, OTerm 24 B) and
 kernels_sweep.hip.h (SweepParams: slot byte offsets at +0x40).
 """
 import os
 import sys
 
-OP_DENSE_REG, OP_DENSE_LANE, OP_DIAG = 0, 1, 2
 # streaming tile loads/stores are non-temporal (each byte is touched once per sweep)
 NT = '' if os.environ.get('QH_ISLAND_NT', '1') == '0' else ' nt'
+T0 = 40
+TEMP_LO, TEMP_HI = 16, 39
 
 
 def T(k):
-  return 64 + 4 * k
+  return T0 + 4 * k
 
 
 def X(k):
@@ -38,6 +41,10 @@ def X(k):
 
 def Y(k):
   return f'v[{T(k) + 2}:{T(k) + 3}]'
+
+
+def V2(i):
+  return f'v[{i}:{i + 1}]'
 
 
 class Asm:
@@ -55,50 +62,76 @@ def L(name):
   return f'{name}_%='
 
 
-def cmul_pair(a, slots, fr, fi):
-  """slot *= (fr,fi) for 1..4 slots, interleaved; temps v[28:35]."""
-  tmps = ['v[28:29]', 'v[30:31]', 'v[32:33]', 'v[34:35]']
+# --- VGPR temporaries by context -------------------------------------------------------
+# common
+V_A, V_B = 16, 17
+# dense register op: 4 result temporaries
+R_T = [30, 32, 34, 36]
+# dense lane op
+LN_ADDR = 16
+LN_TMP = 17
+LN_COEF = {'car': 18, 'cai': 20, 'cbr': 22, 'cbi': 24}
+LN_BUF = [26, 30]          # two shuffle buffers of 4 dwords
+LN_T = [34, 36]
+# diagonal op
+D_C = (18, 20)             # c = cr + i ci
+D_U = (22, 24)             # wave-uniform u
+D_F = (26, 28)             # per-lane factor f
+D_TMP = [30, 32, 34, 36]   # cmul temporaries (4 slots interleaved)
+D_LTAB = 34                # lane-table entry lands in v[34:37] (free until the apply phase)
+
+
+def cmul_slots(a, slots, fr, fi):
+  """slot *= (fr,fi) for 1..4 slots, interleaved to hide the FP64 latency."""
   assert len(slots) <= 4
-  for t, k in zip(tmps, slots):
+  tm = [V2(t) for t in D_TMP]
+  for t, k in zip(tm, slots):
     a(f'v_mul_f64 {t}, {X(k)}, {fr}')
-  for t, k in zip(tmps, slots):
+  for t, k in zip(tm, slots):
     a(f'v_fma_f64 {t}, -{Y(k)}, {fi}, {t}')
-  for t, k in zip(tmps, slots):
+  for t, k in zip(tm, slots):
     a(f'v_mul_f64 {Y(k)}, {Y(k)}, {fr}')
-  for t, k in zip(tmps, slots):
+  for t, k in zip(tm, slots):
     a(f'v_fma_f64 {Y(k)}, {X(k)}, {fi}, {Y(k)}')
-  for t, k in zip(tmps, slots):
+  for t, k in zip(tm, slots):
     a(f'v_mov_b64 {X(k)}, {t}')
 
 
-def cmul_uniform(a, ure, uim, sre, sim, tmp='v[28:29]'):
-  """(ure,uim) *= (sre,sim): VGPR-held wave-uniform value times SGPR pair."""
-  a(f'v_mul_f64 {tmp}, {ure}, {sre}')
-  a(f'v_fma_f64 {tmp}, -{uim}, {sim}, {tmp}')
-  a(f'v_mul_f64 {uim}, {uim}, {sre}')
-  a(f'v_fma_f64 {uim}, {ure}, {sim}, {uim}')
-  a(f'v_mov_b64 {ure}, {tmp}')
+def cmul_vv(a, xr, xi, fr, fi, tmp):
+  """(xr,xi) *= (fr,fi), all 64-bit register pairs (VGPR or SGPR factor)."""
+  a(f'v_mul_f64 {tmp}, {xr}, {fr}')
+  a(f'v_fma_f64 {tmp}, -{xi}, {fi}, {tmp}')
+  a(f'v_mul_f64 {xi}, {xi}, {fr}')
+  a(f'v_fma_f64 {xi}, {xr}, {fi}, {xi}')
+  a(f'v_mov_b64 {xr}, {tmp}')
 
 
 def gen(rb):
   nr = 1 << rb
   a = Asm()
   batch = min(8, nr)
-  # ---- prologue: parameters -------------------------------------------------
+
+  def tile_io(store):
+    for j in range(nr // batch):
+      a(f's_load_dwordx{2 * batch} s[52:{52 + 2 * batch - 1}], %2, {0x40 + 8 * batch * j}')
+      a('s_waitcnt lgkmcnt(0)')
+      for i in range(batch):
+        k = batch * j + i
+        a(f's_add_u32 s98, %0, s{52 + 2 * i}')
+        a(f's_addc_u32 s99, %1, s{53 + 2 * i}')
+        if store:
+          a(f'global_store_dwordx4 %4, v[{T(k)}:{T(k) + 3}], s[98:99]' + NT)
+        else:
+          a(f'global_load_dwordx4 v[{T(k)}:{T(k) + 3}], %4, s[98:99]' + NT)
+
+  # ---- prologue: parameters, then one 1-KiB global_load_dwordx4 per slot ------------
   a('s_load_dwordx4 s[36:39], %2, 0x0')   # ops cursor, groups base
   a('s_load_dwordx2 s[40:41], %2, 0x10')  # oterms base
   a('s_load_dwordx2 s[42:43], %2, 0x18')  # s42 = ops remaining, s43 = tables - groups (bytes)
-  # ---- load the tile: one 1-KiB global_load_dwordx4 per slot ----------------
-  for j in range(nr // batch):
-    a(f's_load_dwordx{2 * batch} s[52:{52 + 2 * batch - 1}], %2, {0x40 + 8 * batch * j}')
-    a('s_waitcnt lgkmcnt(0)')
-    for i in range(batch):
-      k = batch * j + i
-      a(f's_add_u32 s98, %0, s{52 + 2 * i}')
-      a(f's_addc_u32 s99, %1, s{53 + 2 * i}')
-      a(f'global_load_dwordx4 v[{T(k)}:{T(k) + 3}], %4, s[98:99]' + NT)
+  tile_io(store=False)
   a('s_waitcnt vmcnt(0)')
-  # ---- op loop ------------------------------------------------------------------
+
+  # ---- op loop ----------------------------------------------------------------------
   a.label('L_op')
   a('s_cmp_eq_u32 s42, 0')
   a(f's_cbranch_scc1 {L("L_done")}')
@@ -108,10 +141,10 @@ def gen(rb):
   a('s_cmp_eq_u32 s44, 2')
   a(f's_cbranch_scc1 {L("L_diag")}')
   # control predicate of this thread: (it & cm_thread) == cm_thread  -> s[68:69]
-  a('v_and_b32 v16, s48, %6')
-  a('v_and_b32 v17, s49, %7')
-  a('v_cmp_eq_u32 vcc, s48, v16')
-  a('v_cmp_eq_u32_e64 s[72:73], s49, v17')
+  a(f'v_and_b32 v{V_A}, s48, %6')
+  a(f'v_and_b32 v{V_B}, s49, %7')
+  a(f'v_cmp_eq_u32 vcc, s48, v{V_A}')
+  a(f'v_cmp_eq_u32_e64 s[72:73], s49, v{V_B}')
   a('s_nop 1')
   a('s_and_b64 s[68:69], vcc, s[72:73]')
   a('s_cmp_eq_u32 s44, 1')
@@ -125,9 +158,10 @@ def gen(rb):
   a('s_sub_u32 s42, s42, 1')
   a(f's_branch {L("L_op")}')
 
-  # ---- dense 2x2 on register bit b: in-place butterflies --------------------------
+  # ---- dense 2x2 on register bit b: in-place butterflies ----------------------------
   g = {'g0r': 's[52:53]', 'g0i': 's[54:55]', 'g1r': 's[56:57]', 'g1i': 's[58:59]',
        'g2r': 's[60:61]', 'g2i': 's[62:63]', 'g3r': 's[64:65]', 'g3i': 's[66:67]'}
+  t0, t1, t2, t3 = (V2(t) for t in R_T)
   for b in range(rb):
     a.label(f'L_reg{b}')
     for h in range(nr // 2):
@@ -138,7 +172,6 @@ def gen(rb):
       a('s_cmp_eq_u32 s74, 0')
       a(f's_cbranch_scc0 {L(skip)}')
       ar, ai, br, bi = X(k0), Y(k0), X(k1), Y(k1)
-      t0, t1, t2, t3 = 'v[32:33]', 'v[34:35]', 'v[36:37]', 'v[38:39]'
       a(f'v_mul_f64 {t0}, {g["g0r"]}, {ar}')
       a(f'v_mul_f64 {t1}, {g["g0r"]}, {ai}')
       a(f'v_mul_f64 {t2}, {g["g2r"]}, {ar}')
@@ -164,56 +197,54 @@ def gen(rb):
       a.label(skip)
     a(f's_branch {L("L_next")}')
 
-  # ---- dense 2x2 on a lane bit: partner via ds_bpermute ------------------------------
+  # ---- dense 2x2 on a lane bit: partner via ds_bpermute -------------------------------
   a.label('L_lane')
-  a('s_lshl_b32 s74, 1, s45')           # m = 1 << tb
-  a('v_xor_b32 v48, s74, %5')
-  a('v_lshlrev_b32 v48, 2, v48')        # bpermute byte address of the partner lane
-  a('v_and_b32 v49, s74, %5')
-  a('v_cmp_ne_u32 vcc, 0, v49')         # this lane holds the "1" element of the pair
+  a('s_lshl_b32 s74, 1, s45')                     # m = 1 << tb
+  a(f'v_xor_b32 v{LN_ADDR}, s74, %5')
+  a(f'v_lshlrev_b32 v{LN_ADDR}, 2, v{LN_ADDR}')   # bpermute byte address of the partner lane
+  a(f'v_and_b32 v{LN_TMP}, s74, %5')
+  a(f'v_cmp_ne_u32 vcc, 0, v{LN_TMP}')            # this lane holds the "1" element of the pair
   # new = ca*mine + cb*other ; ca = hi ? g3 : g0 ; cb = hi ? g2 : g1
-  coef = {'car': 50, 'cai': 52, 'cbr': 54, 'cbi': 56}
   src = {'car': (52, 64), 'cai': (54, 66), 'cbr': (56, 60), 'cbi': (58, 62)}
-  for name, v in coef.items():
+  for name, v in LN_COEF.items():
     lo, hi = src[name]
     for d in range(2):
       a(f'v_mov_b32 v{v + d}, s{lo + d}')
-      a(f'v_mov_b32 v49, s{hi + d}')
-      a(f'v_cndmask_b32 v{v + d}, v{v + d}, v49, vcc')
-  car, cai, cbr, cbi = 'v[50:51]', 'v[52:53]', 'v[54:55]', 'v[56:57]'
+      a(f'v_mov_b32 v{LN_TMP}, s{hi + d}')
+      a(f'v_cndmask_b32 v{v + d}, v{v + d}, v{LN_TMP}, vcc')
+  car, cai, cbr, cbi = (V2(LN_COEF[n]) for n in ('car', 'cai', 'cbr', 'cbi'))
 
   def shuf(k, buf):
     for d in range(4):
-      a(f'ds_bpermute_b32 v{buf + d}, v48, v{T(k) + d}')
+      a(f'ds_bpermute_b32 v{buf + d}, v{LN_ADDR}, v{T(k) + d}')
 
   def combine(k, buf):
-    orr, oi = f'v[{buf}:{buf + 1}]', f'v[{buf + 2}:{buf + 3}]'
-    t0, t1 = 'v[32:33]', 'v[34:35]'
-    a(f'v_mul_f64 {t0}, {car}, {X(k)}')
-    a(f'v_mul_f64 {t1}, {car}, {Y(k)}')
-    a(f'v_fma_f64 {t0}, -{cai}, {Y(k)}, {t0}')
-    a(f'v_fma_f64 {t1}, {cai}, {X(k)}, {t1}')
-    a(f'v_fma_f64 {t0}, {cbr}, {orr}, {t0}')
-    a(f'v_fma_f64 {t1}, {cbr}, {oi}, {t1}')
-    a(f'v_fma_f64 {t0}, -{cbi}, {oi}, {t0}')
-    a(f'v_fma_f64 {t1}, {cbi}, {orr}, {t1}')
+    orr, oi = V2(buf), V2(buf + 2)
+    u0, u1 = V2(LN_T[0]), V2(LN_T[1])
+    a(f'v_mul_f64 {u0}, {car}, {X(k)}')
+    a(f'v_mul_f64 {u1}, {car}, {Y(k)}')
+    a(f'v_fma_f64 {u0}, -{cai}, {Y(k)}, {u0}')
+    a(f'v_fma_f64 {u1}, {cai}, {X(k)}, {u1}')
+    a(f'v_fma_f64 {u0}, {cbr}, {orr}, {u0}')
+    a(f'v_fma_f64 {u1}, {cbr}, {oi}, {u1}')
+    a(f'v_fma_f64 {u0}, -{cbi}, {oi}, {u0}')
+    a(f'v_fma_f64 {u1}, {cbi}, {orr}, {u1}')
     a('s_and_saveexec_b64 s[70:71], s[68:69]')
-    a(f'v_mov_b64 {X(k)}, {t0}')
-    a(f'v_mov_b64 {Y(k)}, {t1}')
+    a(f'v_mov_b64 {X(k)}, {u0}')
+    a(f'v_mov_b64 {Y(k)}, {u1}')
     a('s_mov_b64 exec, s[70:71]')
 
   a('s_cmp_eq_u32 s46, 0')
   a(f's_cbranch_scc0 {L("L_lane_ctl")}')
   # fast path (no register-bit controls): shuffles of slot k+1 in flight while slot k combines
-  bufs = [40, 44]
-  shuf(0, bufs[0])
+  shuf(0, LN_BUF[0])
   for k in range(nr):
     if k + 1 < nr:
-      shuf(k + 1, bufs[(k + 1) & 1])
+      shuf(k + 1, LN_BUF[(k + 1) & 1])
       a('s_waitcnt lgkmcnt(4)')
     else:
       a('s_waitcnt lgkmcnt(0)')
-    combine(k, bufs[k & 1])
+    combine(k, LN_BUF[k & 1])
   a(f's_branch {L("L_next")}')
   a.label('L_lane_ctl')
   for k in range(nr):
@@ -221,47 +252,53 @@ def gen(rb):
     a(f's_andn2_b32 s74, s46, {k}')
     a('s_cmp_eq_u32 s74, 0')
     a(f's_cbranch_scc0 {L(skip)}')
-    shuf(k, 40)
+    shuf(k, LN_BUF[0])
     a('s_waitcnt lgkmcnt(0)')
-    combine(k, 40)
+    combine(k, LN_BUF[0])
     a.label(skip)
   a(f's_branch {L("L_next")}')
 
   # ---- diagonal op: groups of phase factors -------------------------------------------
   # SGPRs here: s[48:49] tables base, s[52:67] group header (lane_mask reg_mask
   # oterm_off n_oterms re(2) im(2) flags ltab_off ntab tab_shift tab_off[4]),
-  # s[76:91] chunk-table entries / oterm scratch, s[92:93] group cursor, s96 counter.
+  # s[76:91] chunk-table entries / oterm scratch, s[92:93] group cursor, s96 counter,
+  # s72 = reg_mask of the group being applied (its header registers are already
+  # being refilled with the NEXT group's header during the apply phase).
+  cr, ci = V2(D_C[0]), V2(D_C[1])
+  ur, ui = V2(D_U[0]), V2(D_U[1])
+  fr, fi = V2(D_F[0]), V2(D_F[1])
+  dt = V2(D_TMP[0])
   a.label('L_diag')
-  a('v_mov_b32 v20, 0')
-  a('v_mov_b32 v21, 0x3ff00000')   # c = 1.0 + 0.0i  (cr = v[20:21], ci = v[22:23])
-  a('v_mov_b32 v22, 0')
-  a('v_mov_b32 v23, 0')
-  a('s_mov_b32 s75, 0')            # c modified?
+  a(f'v_mov_b32 v{D_C[0]}, 0')
+  a(f'v_mov_b32 v{D_C[0] + 1}, 0x3ff00000')   # c = 1.0 + 0.0i
+  a(f'v_mov_b32 v{D_C[1]}, 0')
+  a(f'v_mov_b32 v{D_C[1] + 1}, 0')
+  a('s_mov_b32 s75, 0')                        # c modified?
   a('s_cmp_eq_u32 s47, 0')
   a(f's_cbranch_scc1 {L("L_next")}')
-  a('s_add_u32 s48, s38, s43')     # tables base = groups base + rel
+  a('s_add_u32 s48, s38, s43')                 # tables base = groups base + rel
   a('s_addc_u32 s49, s39, 0')
-  a('s_lshl_b32 s74, s50, 6')      # group_off * sizeof(DGroup)=64
+  a('s_lshl_b32 s74, s50, 6')                  # group_off * sizeof(DGroup)=64
   a('s_add_u32 s92, s38, s74')
   a('s_addc_u32 s93, s39, 0')
   a('s_mov_b32 s96, 0')
-  a.label('L_grp')
   a('s_load_dwordx16 s[52:67], s[92:93], 0x0')
+  a.label('L_grp')
   a('s_waitcnt lgkmcnt(0)')
-  a('v_mov_b32 v24, s56')
-  a('v_mov_b32 v25, s57')          # u = v[24:25] + i v[26:27]  (wave-uniform value)
-  a('v_mov_b32 v26, s58')
-  a('v_mov_b32 v27, s59')
-  a('s_bitcmp1_b32 s60, 0')        # LTAB: start the 1-KiB lane-table load early
+  a(f'v_mov_b32 v{D_U[0]}, s56')
+  a(f'v_mov_b32 v{D_U[0] + 1}, s57')           # u = phi0 (wave-uniform value held in VGPRs)
+  a(f'v_mov_b32 v{D_U[1]}, s58')
+  a(f'v_mov_b32 v{D_U[1] + 1}, s59')
+  a('s_bitcmp1_b32 s60, 0')                    # LTAB: start the 1-KiB lane-table load early
   a(f's_cbranch_scc0 {L("L_g1")}')
   a('s_lshl_b32 s74, s61, 4')
   a('s_add_u32 s98, s48, s74')
   a('s_addc_u32 s99, s49, 0')
-  a('global_load_dwordx4 v[40:43], %4, s[98:99]')
+  a(f'global_load_dwordx4 v[{D_LTAB}:{D_LTAB + 3}], %4, s[98:99]')
   a.label('L_g1')
   a('s_cmp_eq_u32 s62, 0')
   a(f's_cbranch_scc1 {L("L_g2")}')
-  for t in range(4):               # issue all chunk-table lookups, then one wait
+  for t in range(4):                           # issue all chunk-table lookups, then one wait
     if t:
       a(f's_cmp_le_u32 s62, {t}')
       a(f's_cbranch_scc1 {L("L_g1w")}')
@@ -277,11 +314,11 @@ def gen(rb):
     if t:
       a(f's_cmp_le_u32 s62, {t}')
       a(f's_cbranch_scc1 {L("L_g2")}')
-    cmul_uniform(a, 'v[24:25]', 'v[26:27]', f's[{76 + 4 * t}:{77 + 4 * t}]', f's[{78 + 4 * t}:{79 + 4 * t}]')
+    cmul_vv(a, ur, ui, f's[{76 + 4 * t}:{77 + 4 * t}]', f's[{78 + 4 * t}:{79 + 4 * t}]', dt)
   a.label('L_g2')
   a('s_cmp_eq_u32 s55, 0')
   a(f's_cbranch_scc1 {L("L_grp_f")}')
-  a('s_mul_i32 s74, s54, 24')      # oterm_off * sizeof(OTerm)=24
+  a('s_mul_i32 s74, s54, 24')                  # oterm_off * sizeof(OTerm)=24
   a('s_add_u32 s94, s40, s74')
   a('s_addc_u32 s95, s41, 0')
   a('s_mov_b32 s97, 0')
@@ -292,7 +329,7 @@ def gen(rb):
   a('s_and_b64 s[72:73], %3, s[84:85]')
   a('s_cmp_eq_u64 s[72:73], s[84:85]')
   a(f's_cbranch_scc0 {L("L_ot_n")}')
-  cmul_uniform(a, 'v[24:25]', 'v[26:27]', 's[88:89]', 's[90:91]')
+  cmul_vv(a, ur, ui, 's[88:89]', 's[90:91]', dt)
   a.label('L_ot_n')
   a('s_add_u32 s94, s94, 24')
   a('s_addc_u32 s95, s95, 0')
@@ -300,78 +337,74 @@ def gen(rb):
   a('s_cmp_lt_u32 s97, s55')
   a(f's_cbranch_scc1 {L("L_ot")}')
   a.label('L_grp_f')
-  # per-lane factor f (fr = v[58:59], fi = v[60:61])
   a('s_bitcmp1_b32 s60, 0')
   a(f's_cbranch_scc0 {L("L_g3")}')
-  a('s_waitcnt vmcnt(0)')          # f = ltab[lane] * u
-  a('v_mul_f64 v[58:59], v[40:41], v[24:25]')
-  a('v_mul_f64 v[60:61], v[40:41], v[26:27]')
-  a('v_fma_f64 v[58:59], -v[42:43], v[26:27], v[58:59]')
-  a('v_fma_f64 v[60:61], v[42:43], v[24:25], v[60:61]')
+  a('s_waitcnt vmcnt(0)')                      # f = ltab[lane] * u
+  lt_r, lt_i = V2(D_LTAB), V2(D_LTAB + 2)
+  a(f'v_mul_f64 {fr}, {lt_r}, {ur}')
+  a(f'v_mul_f64 {fi}, {lt_r}, {ui}')
+  a(f'v_fma_f64 {fr}, -{lt_i}, {ui}, {fr}')
+  a(f'v_fma_f64 {fi}, {lt_i}, {ur}, {fi}')
   a(f's_branch {L("L_g4")}')
-  a.label('L_g3')                  # f = lane_ok ? u : 1
-  a('v_and_b32 v16, s52, %5')
-  a('v_cmp_eq_u32 vcc, s52, v16')
-  a('v_mov_b32 v17, 0x3ff00000')
-  a('v_cndmask_b32 v58, 0, v24, vcc')
-  a('v_cndmask_b32 v59, v17, v25, vcc')
-  a('v_cndmask_b32 v60, 0, v26, vcc')
-  a('v_cndmask_b32 v61, 0, v27, vcc')
+  a.label('L_g3')                              # f = lane_ok ? u : 1
+  a(f'v_and_b32 v{V_A}, s52, %5')
+  a(f'v_cmp_eq_u32 vcc, s52, v{V_A}')
+  a(f'v_mov_b32 v{V_B}, 0x3ff00000')
+  a(f'v_cndmask_b32 v{D_F[0]}, 0, v{D_U[0]}, vcc')
+  a(f'v_cndmask_b32 v{D_F[0] + 1}, v{V_B}, v{D_U[0] + 1}, vcc')
+  a(f'v_cndmask_b32 v{D_F[1]}, 0, v{D_U[1]}, vcc')
+  a(f'v_cndmask_b32 v{D_F[1] + 1}, 0, v{D_U[1] + 1}, vcc')
   a.label('L_g4')
-  a('s_cmp_eq_u32 s53, 0')
-  a(f's_cbranch_scc0 {L("L_grp_r")}')
-  # reg_mask == 0: c *= f
-  a('v_mul_f64 v[28:29], v[20:21], v[58:59]')
-  a('v_fma_f64 v[28:29], -v[22:23], v[60:61], v[28:29]')
-  a('v_mul_f64 v[22:23], v[22:23], v[58:59]')
-  a('v_fma_f64 v[22:23], v[20:21], v[60:61], v[22:23]')
-  a('v_mov_b64 v[20:21], v[28:29]')
-  a('s_mov_b32 s75, 1')
-  a(f's_branch {L("L_grp_n")}')
-  a.label('L_grp_r')
-  for b in range(rb):              # single register bit: straight-line, no per-slot branches
-    a(f's_cmp_eq_u32 s53, {1 << b}')
-    a(f's_cbranch_scc1 {L(f"L_gsb{b}")}')
-  for k in range(nr):              # general register mask
-    skip = f'L_g_{k}'
-    a(f's_andn2_b32 s74, s53, {k}')
-    a('s_cmp_eq_u32 s74, 0')
-    a(f's_cbranch_scc0 {L(skip)}')
-    cmul_pair(a, [k], 'v[58:59]', 'v[60:61]')
-    a.label(skip)
-  a(f's_branch {L("L_grp_n")}')
-  for b in range(rb):
-    a.label(f'L_gsb{b}')
-    slots = [k for k in range(nr) if (k >> b) & 1]
-    for i in range(0, len(slots), 4):
-      cmul_pair(a, slots[i:i + 4], 'v[58:59]', 'v[60:61]')
-    if b != rb - 1:
-      a(f's_branch {L("L_grp_n")}')
-  a.label('L_grp_n')
+  # the header is consumed: remember reg_mask, advance, and prefetch the NEXT group's
+  # header into the same SGPRs while the VALU applies this group's factor
+  a('s_mov_b32 s72, s53')
   a('s_add_u32 s92, s92, 64')
   a('s_addc_u32 s93, s93, 0')
   a('s_add_u32 s96, s96, 1')
+  a('s_cmp_lt_u32 s96, s47')
+  a(f's_cbranch_scc0 {L("L_g5")}')
+  a('s_load_dwordx16 s[52:67], s[92:93], 0x0')
+  a.label('L_g5')
+  a('s_cmp_eq_u32 s72, 0')
+  a(f's_cbranch_scc0 {L("L_grp_r")}')
+  cmul_vv(a, cr, ci, fr, fi, dt)               # reg_mask == 0: c *= f
+  a('s_mov_b32 s75, 1')
+  a(f's_branch {L("L_grp_n")}')
+  a.label('L_grp_r')
+  masks = [1 << b for b in range(rb)] + [(1 << b0) | (1 << b1) for b0 in range(rb) for b1 in range(b0 + 1, rb)]
+  for m in masks:                              # 1- and 2-bit register masks: straight-line code
+    a(f's_cmp_eq_u32 s72, {m}')
+    a(f's_cbranch_scc1 {L(f"L_gm{m}")}')
+  for k in range(nr):                          # any other register mask
+    skip = f'L_g_{k}'
+    a(f's_andn2_b32 s74, s72, {k}')
+    a('s_cmp_eq_u32 s74, 0')
+    a(f's_cbranch_scc0 {L(skip)}')
+    cmul_slots(a, [k], fr, fi)
+    a.label(skip)
+  a(f's_branch {L("L_grp_n")}')
+  for m in masks:
+    a.label(f'L_gm{m}')
+    slots = [k for k in range(nr) if (k & m) == m]
+    for i in range(0, len(slots), 4):
+      cmul_slots(a, slots[i:i + 4], fr, fi)
+    a(f's_branch {L("L_grp_n")}')
+  a.label('L_grp_n')
   a('s_cmp_lt_u32 s96, s47')
   a(f's_cbranch_scc1 {L("L_grp")}')
   a('s_cmp_eq_u32 s75, 0')
   a(f's_cbranch_scc1 {L("L_next")}')
   for k in range(0, nr, 4):
-    cmul_pair(a, list(range(k, min(k + 4, nr))), 'v[20:21]', 'v[22:23]')
+    cmul_slots(a, list(range(k, min(k + 4, nr))), cr, ci)
   a(f's_branch {L("L_next")}')
 
-  # ---- store the tile ----------------------------------------------------------------------
+  # ---- store the tile -------------------------------------------------------------------
   a.label('L_done')
-  for j in range(nr // batch):
-    a(f's_load_dwordx{2 * batch} s[52:{52 + 2 * batch - 1}], %2, {0x40 + 8 * batch * j}')
-    a('s_waitcnt lgkmcnt(0)')
-    for i in range(batch):
-      k = batch * j + i
-      a(f's_add_u32 s98, %0, s{52 + 2 * i}')
-      a(f's_addc_u32 s99, %1, s{53 + 2 * i}')
-      a(f'global_store_dwordx4 %4, v[{T(k)}:{T(k) + 3}], s[98:99]' + NT)
+  tile_io(store=True)
   a('s_nop 0')
 
-  clob = [f'v{i}' for i in range(16, 64 + 4 * nr)] + [f's{i}' for i in range(36, 100)] + ['vcc', 'scc', 'memory']
+  clob = ([f'v{i}' for i in range(TEMP_LO, T0 + 4 * nr)] + [f's{i}' for i in range(36, 100)] +
+          ['vcc', 'scc', 'memory'])
   body = '\n'.join(f'    "{ln}\\n\\t"' for ln in a.lines)
   cl = ', '.join(f'"{c}"' for c in clob)
   return (f'// GENERATED by tools/gen_sweep_asm.py (RB={rb}) -- do not edit.\n'
