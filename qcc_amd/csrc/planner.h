@@ -48,6 +48,10 @@ constexpr int kMaxRegBits = 5; // 32 amplitudes (128 VGPRs of data) per lane
 constexpr int kMaxSweepOps = 1024;
 
 enum : uint32_t { OP_DENSE_REG = 0, OP_DENSE_LANE = 1, OP_DIAG = 2 };
+// A DIAG op directly followed by an uncontrolled dense op on a LANE bit does not
+// apply its per-lane factor c to the 2^RB slots: the dense op folds it into its
+// per-lane matrix coefficients (H.diag(c)), two complex products per lane.
+enum : uint32_t { OPF_DEFER_C = 1, OPF_USE_C = 2, OPF_REAL = 4 };  // REAL: all four entries real
 
 // ---- device-visible records (plain data, copied verbatim to HBM) -------------
 // A factor that multiplies amplitudes whose index has all bits of `mask` set;
@@ -79,7 +83,7 @@ struct SweepOp {
   uint32_t n_groups;   // diag
   uint64_t cm_thread;  // dense: control mask over (shard|outside|lane) index bits
   uint32_t group_off;  // diag
-  uint32_t pad;
+  uint32_t flags;      // OPF_*
   double g[8];         // dense: the 2x2
 };
 
@@ -281,7 +285,10 @@ class Planner {
     for (const GateRec *r : taken) {
       const bool diag = plan_diag(r->g, r->tgt);
       if (!diag) {
+        const size_t n_ops_before = sp->ops.size();
         flush_diag(&pending, 1ull << r->tgt, sp);
+        // non-zero only when THIS flush emitted a DIAG op right in front of the dense op
+        const size_t n_ops_after_flush = sp->ops.size() > n_ops_before ? sp->ops.size() : 0;
         SweepOp op{};
         uint32_t lane, reg; uint64_t outside;
         split_mask(*sp, r->ctl_mask, &lane, &reg, &outside);
@@ -290,6 +297,12 @@ class Planner {
         memcpy(op.g, r->g, sizeof op.g);
         if (r->tgt < kLaneBits) { op.kind = OP_DENSE_LANE; op.tb = r->tgt; }
         else { op.kind = OP_DENSE_REG; op.tb = reg_index(*sp, r->tgt); }
+        if (r->g[1] == 0.0 && r->g[3] == 0.0 && r->g[5] == 0.0 && r->g[7] == 0.0) op.flags |= OPF_REAL;
+        if (op.kind == OP_DENSE_LANE && op.cm_thread == 0 && op.cm_reg == 0 && !sp->ops.empty() &&
+            sp->ops.back().kind == OP_DIAG && sp->ops.size() == n_ops_after_flush) {
+          sp->ops.back().flags |= OPF_DEFER_C;
+          op.flags |= OPF_USE_C;
+        }
         sp->ops.push_back(op);
         continue;
       }

@@ -85,25 +85,23 @@ def cmul_slots(a, slots, fr, fi):
   """slot *= (fr,fi) for 1..4 slots, interleaved to hide the FP64 latency."""
   assert len(slots) <= 4
   tm = [V2(t) for t in D_TMP]
+  # t = y*fi ; y = y*fr ; y += x*fi ; x = x*fr - t   (4 FP64 ops, result in place)
   for t, k in zip(tm, slots):
-    a(f'v_mul_f64 {t}, {X(k)}, {fr}')
-  for t, k in zip(tm, slots):
-    a(f'v_fma_f64 {t}, -{Y(k)}, {fi}, {t}')
+    a(f'v_mul_f64 {t}, {Y(k)}, {fi}')
   for t, k in zip(tm, slots):
     a(f'v_mul_f64 {Y(k)}, {Y(k)}, {fr}')
   for t, k in zip(tm, slots):
     a(f'v_fma_f64 {Y(k)}, {X(k)}, {fi}, {Y(k)}')
   for t, k in zip(tm, slots):
-    a(f'v_mov_b64 {X(k)}, {t}')
+    a(f'v_fma_f64 {X(k)}, {X(k)}, {fr}, -{t}')
 
 
 def cmul_vv(a, xr, xi, fr, fi, tmp):
   """(xr,xi) *= (fr,fi), all 64-bit register pairs (VGPR or SGPR factor)."""
-  a(f'v_mul_f64 {tmp}, {xr}, {fr}')
-  a(f'v_fma_f64 {tmp}, -{xi}, {fi}, {tmp}')
+  a(f'v_mul_f64 {tmp}, {xi}, {fi}')
   a(f'v_mul_f64 {xi}, {xi}, {fr}')
   a(f'v_fma_f64 {xi}, {xr}, {fi}, {xi}')
-  a(f'v_mov_b64 {xr}, {tmp}')
+  a(f'v_fma_f64 {xr}, {xr}, {fr}, -{tmp}')
 
 
 def gen(rb):
@@ -135,7 +133,7 @@ def gen(rb):
   a.label('L_op')
   a('s_cmp_eq_u32 s42, 0')
   a(f's_cbranch_scc1 {L("L_done")}')
-  a('s_load_dwordx8 s[44:51], s[36:37], 0x0')    # kind tb cm_reg n_groups cm_thread(2) group_off pad
+  a('s_load_dwordx8 s[44:51], s[36:37], 0x0')    # kind tb cm_reg n_groups cm_thread(2) group_off flags
   a('s_load_dwordx16 s[52:67], s[36:37], 0x20')  # g[8]
   a('s_waitcnt lgkmcnt(0)')
   a('s_cmp_eq_u32 s44, 2')
@@ -147,6 +145,13 @@ def gen(rb):
   a(f'v_cmp_eq_u32_e64 s[72:73], s49, v{V_B}')
   a('s_nop 1')
   a('s_and_b64 s[68:69], vcc, s[72:73]')
+  # REAL fast paths: all four matrix entries real (h, x, ry, cx ...) and no control at all
+  a('s_or_b32 s74, s48, s49')
+  a('s_or_b32 s74, s74, s46')
+  a('s_andn2_b32 s73, 4, s51')                # 0 iff OPF_REAL set
+  a('s_or_b32 s74, s74, s73')
+  a('s_cmp_eq_u32 s74, 0')
+  a(f's_cbranch_scc1 {L("L_real")}')
   a('s_cmp_eq_u32 s44, 1')
   a(f's_cbranch_scc1 {L("L_lane")}')
   for b in range(rb):
@@ -197,6 +202,73 @@ def gen(rb):
       a.label(skip)
     a(f's_branch {L("L_next")}')
 
+  # ---- REAL uncontrolled dense ops: half the arithmetic, results in place ---------------
+  a.label('L_real')
+  a('s_cmp_eq_u32 s44, 1')
+  a(f's_cbranch_scc1 {L("L_lane_real")}')
+  for b in range(rb):
+    a(f's_cmp_eq_u32 s45, {b}')
+    a(f's_cbranch_scc1 {L(f"L_rr{b}")}')
+  a(f's_branch {L("L_next")}')
+  for b in range(rb):
+    a.label(f'L_rr{b}')
+    pairs = []
+    for h in range(nr // 2):
+      k0 = ((h >> b) << (b + 1)) | (h & ((1 << b) - 1))
+      pairs.append((k0, k0 | (1 << b)))
+    for i in range(0, len(pairs), 2):           # two pairs interleaved (4 temporaries)
+      grp = pairs[i:i + 2]
+      tmps = [(V2(R_T[2 * j]), V2(R_T[2 * j + 1])) for j in range(len(grp))]
+      for (k0, k1), (ta, tb) in zip(grp, tmps):
+        a(f'v_mul_f64 {ta}, {g["g0r"]}, {X(k0)}')
+        a(f'v_mul_f64 {tb}, {g["g0r"]}, {Y(k0)}')
+      for (k0, k1), (ta, tb) in zip(grp, tmps):
+        a(f'v_fma_f64 {ta}, {g["g1r"]}, {X(k1)}, {ta}')
+        a(f'v_fma_f64 {tb}, {g["g1r"]}, {Y(k1)}, {tb}')
+      for (k0, k1), (ta, tb) in zip(grp, tmps):
+        a(f'v_mul_f64 {X(k1)}, {g["g3r"]}, {X(k1)}')
+        a(f'v_mul_f64 {Y(k1)}, {g["g3r"]}, {Y(k1)}')
+      for (k0, k1), (ta, tb) in zip(grp, tmps):
+        a(f'v_fma_f64 {X(k1)}, {g["g2r"]}, {X(k0)}, {X(k1)}')
+        a(f'v_fma_f64 {Y(k1)}, {g["g2r"]}, {Y(k0)}, {Y(k1)}')
+      for (k0, k1), (ta, tb) in zip(grp, tmps):
+        a(f'v_mov_b64 {X(k0)}, {ta}')
+        a(f'v_mov_b64 {Y(k0)}, {tb}')
+    a(f's_branch {L("L_next")}')
+  # lane bit, real: new = ca*mine + cb*other with real per-lane ca, cb -- 4 FP64 ops per slot
+  a.label('L_lane_real')
+  a('s_lshl_b32 s74, 1, s45')
+  a(f'v_xor_b32 v{LN_ADDR}, s74, %5')
+  a(f'v_lshlrev_b32 v{LN_ADDR}, 2, v{LN_ADDR}')
+  a(f'v_and_b32 v{LN_TMP}, s74, %5')
+  a(f'v_cmp_ne_u32 vcc, 0, v{LN_TMP}')
+  a('s_bitcmp1_b32 s51, 1')                     # USE_C needs complex coefficients: generic path
+  a(f's_cbranch_scc1 {L("L_lane_c1")}')
+  for v, (lo, hi) in ((LN_COEF['car'], (52, 64)), (LN_COEF['cbr'], (56, 60))):
+    for d in range(2):
+      a(f'v_mov_b32 v{v + d}, s{lo + d}')
+      a(f'v_mov_b32 v{LN_TMP}, s{hi + d}')
+      a(f'v_cndmask_b32 v{v + d}, v{v + d}, v{LN_TMP}, vcc')
+  rca, rcb = V2(LN_COEF['car']), V2(LN_COEF['cbr'])
+
+  def shuf_r(k, buf):
+    for d in range(4):
+      a(f'ds_bpermute_b32 v{buf + d}, v{LN_ADDR}, v{T(k) + d}')
+
+  shuf_r(0, LN_BUF[0])
+  for k in range(nr):
+    if k + 1 < nr:
+      shuf_r(k + 1, LN_BUF[(k + 1) & 1])
+      a('s_waitcnt lgkmcnt(4)')
+    else:
+      a('s_waitcnt lgkmcnt(0)')
+    buf = LN_BUF[k & 1]
+    a(f'v_mul_f64 {X(k)}, {rca}, {X(k)}')
+    a(f'v_mul_f64 {Y(k)}, {rca}, {Y(k)}')
+    a(f'v_fma_f64 {X(k)}, {rcb}, {V2(buf)}, {X(k)}')
+    a(f'v_fma_f64 {Y(k)}, {rcb}, {V2(buf + 2)}, {Y(k)}')
+  a(f's_branch {L("L_next")}')
+
   # ---- dense 2x2 on a lane bit: partner via ds_bpermute -------------------------------
   a.label('L_lane')
   a('s_lshl_b32 s74, 1, s45')                     # m = 1 << tb
@@ -204,6 +276,16 @@ def gen(rb):
   a(f'v_lshlrev_b32 v{LN_ADDR}, 2, v{LN_ADDR}')   # bpermute byte address of the partner lane
   a(f'v_and_b32 v{LN_TMP}, s74, %5')
   a(f'v_cmp_ne_u32 vcc, 0, v{LN_TMP}')            # this lane holds the "1" element of the pair
+  a.label('L_lane_c1')
+  # deferred factor c of the preceding DIAG op lives in v[18:21] = the coefficient
+  # registers: move it to v[34:37] and fetch the partner lane's c into v[26:29] first
+  a('s_bitcmp1_b32 s51, 1')
+  a(f's_cbranch_scc0 {L("L_lane_c0")}')
+  a(f'v_mov_b64 {V2(34)}, {V2(D_C[0])}')
+  a(f'v_mov_b64 {V2(36)}, {V2(D_C[1])}')
+  for d in range(4):
+    a(f'ds_bpermute_b32 v{LN_BUF[0] + d}, v{LN_ADDR}, v{34 + d}')
+  a.label('L_lane_c0')
   # new = ca*mine + cb*other ; ca = hi ? g3 : g0 ; cb = hi ? g2 : g1
   src = {'car': (52, 64), 'cai': (54, 66), 'cbr': (56, 60), 'cbi': (58, 62)}
   for name, v in LN_COEF.items():
@@ -213,6 +295,15 @@ def gen(rb):
       a(f'v_mov_b32 v{LN_TMP}, s{hi + d}')
       a(f'v_cndmask_b32 v{v + d}, v{v + d}, v{LN_TMP}, vcc')
   car, cai, cbr, cbi = (V2(LN_COEF[n]) for n in ('car', 'cai', 'cbr', 'cbi'))
+  # USE_C (flags bit 1): the preceding DIAG op left its per-lane factor c un-applied;
+  # H.diag(c) acts as  new = (ca c_mine) mine + (cb c_other) other  -- two complex
+  # products per LANE instead of one per amplitude.
+  a('s_bitcmp1_b32 s51, 1')
+  a(f's_cbranch_scc0 {L("L_lane_nc")}')
+  a('s_waitcnt lgkmcnt(0)')
+  cmul_vv(a, car, cai, V2(34), V2(36), V2(LN_BUF[1]))
+  cmul_vv(a, cbr, cbi, V2(LN_BUF[0]), V2(LN_BUF[0] + 2), V2(LN_BUF[1]))
+  a.label('L_lane_nc')
 
   def shuf(k, buf):
     for d in range(4):
@@ -393,6 +484,8 @@ def gen(rb):
   a('s_cmp_lt_u32 s96, s47')
   a(f's_cbranch_scc1 {L("L_grp")}')
   a('s_cmp_eq_u32 s75, 0')
+  a(f's_cbranch_scc1 {L("L_next")}')
+  a('s_bitcmp1_b32 s51, 0')                    # DEFER_C: the next (lane) op folds c into its matrix
   a(f's_cbranch_scc1 {L("L_next")}')
   for k in range(0, nr, 4):
     cmul_slots(a, list(range(k, min(k + 4, nr))), cr, ci)

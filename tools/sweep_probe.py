@@ -43,3 +43,9 @@ run('H 0-10 + cu1 with outside target', (isH & (tb <= 10)) | (~isH & (cb <= 10) 
 run('cu1 ctl<=10 outside targets only (diag-only sweep)', ~isH & (cb <= 10) & (tb > 10))
 run('cu1 ctl lane, tgt reg', ~isH & (cb <= 5) & (tb >= 6) & (tb <= 10))
 run('cu1 ctl lane, tgt lane', ~isH & (cb <= 5) & (tb <= 5))
+H10 = isH & (tb <= 10)
+run('H + cu1 lane-lane (15)', H10 | (~isH & (cb <= 5) & (tb <= 5)))
+run('H + cu1 lane->reg (30)', H10 | (~isH & (cb <= 5) & (tb >= 6) & (tb <= 10)))
+run('H + cu1 reg-reg (10)', H10 | (~isH & (cb >= 6) & (cb <= 10) & (tb <= 10)))
+run('H + cu1 lane->outside (114)', H10 | (~isH & (cb <= 5) & (tb > 10)))
+run('H + cu1 reg->outside (95)', H10 | (~isH & (cb >= 6) & (cb <= 10) & (tb > 10)))
