@@ -1,0 +1,66 @@
+/*
+ * libq.h -- `libq`-compatible C++ facade over the MI355X engine.
+ *
+ * Same namespace, type names and function signatures as the reference's
+ * src/libq/libq.h:44-69, so a program transpiled by qcc (`--libq=prog.cc`,
+ * src/lib/dumpers.py:40-86) compiles against this header instead and runs on the
+ * GPU:   hipcc prog.cc -I<repo>/include <repo>/qcc_amd/csrc/libq_facade.cc \
+ *              -L<repo>/qcc_amd -lqcc_hip -Wl,-rpath,<repo>/qcc_amd
+ *
+ * Differences (deliberate):
+ *  - the register is DENSE in HBM and complex128 (reference: sparse hash table of
+ *    complex<float>); `qureg` therefore has no state[]/amplitude[]/hash arrays;
+ *  - v / yroot / cv / cv_adj implement what they are named after (sqrt(X), sqrt(Y),
+ *    controlled sqrt(X) and its adjoint, the matrices of src/lib/ops.py:152-162).
+ *    The reference versions apply the gate once per stored state inside a loop
+ *    (gates.cc:9-15,48-54,96-118) and are not usable as a spec;
+ *  - bit order is libq's: target t is index bit t (little-endian).
+ */
+#ifndef QCC_LIBQ_FACADE_H_
+#define QCC_LIBQ_FACADE_H_
+
+#include <complex>
+
+#include "qcc_hip.h"
+
+namespace libq {
+
+typedef std::complex<float> cmplx;
+typedef unsigned long long state_t;
+
+struct qureg_t {
+  int width;          /* number of qubits */
+  int size;           /* basis states with non-negligible probability (updated by print/flush) */
+  int maxsize;
+  int hash_computes;  /* always 0: there is no hash table */
+  qh_handle handle;   /* the HBM-resident state */
+};
+typedef struct qureg_t qureg;
+
+qureg *new_qureg(state_t initval, int width);
+void delete_qureg(qureg *reg);
+void print_qureg(qureg *reg);
+void print_qureg_stats(qureg *reg);
+void flush(qureg *reg);
+
+void x(int target, qureg *reg);
+void y(int target, qureg *reg);
+void z(int target, qureg *reg);
+void h(int target, qureg *reg);
+void t(int target, qureg *reg);
+void v(int target, qureg *reg);
+void yroot(int target, qureg *reg);
+void walsh(int width, qureg *reg);
+void cx(int control, int target, qureg *reg);
+void cz(int control, int target, qureg *reg);
+void ccx(int control0, int control1, int target, qureg *reg);
+void u1(int target, float gamma, qureg *reg);
+void cu1(int control, int target, float gamma, qureg *reg);
+void cv(int control, int target, qureg *reg);
+void cv_adj(int control, int target, qureg *reg);
+
+float probability(cmplx ampl);
+
+}  // namespace libq
+
+#endif  // QCC_LIBQ_FACADE_H_

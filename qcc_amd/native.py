@@ -14,7 +14,8 @@ LIB_PATH = os.environ.get('QCC_HIP_LIB') or os.path.join(PKG, 'libqcc_hip.so')  
 SOURCES = [os.path.join(PKG, 'csrc', f) for f in
            ('engine.hip', 'kernels_gate.hip.h', 'kernels_sweep.hip.h', 'planner.h',
             'sweep_island_rb2.inc', 'sweep_island_rb3.inc', 'sweep_island_rb4.inc',
-            'sweep_island_rb5.inc')]
+            'sweep_island_rb5.inc', 'libq_facade.cc')]
+HEADERS = [os.path.join(ROOT, 'include', 'libq.h')]
 HEADER = os.path.join(ROOT, 'include', 'qcc_hip.h')
 
 QH_OK = 0
@@ -83,12 +84,12 @@ class QhError(RuntimeError):
 
 def build(force=False, verbose=False):
   """Compile the HIP engine for gfx950 in-tree (qcc_amd/libqcc_hip.so)."""
-  deps = SOURCES + [HEADER]
+  deps = SOURCES + [HEADER] + HEADERS
   if (not force and os.path.exists(LIB_PATH)
       and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps)):
     return LIB_PATH
   cmd = ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC',
-         '-o', LIB_PATH, SOURCES[0]]
+         '-o', LIB_PATH, SOURCES[0], SOURCES[-1]]  # engine.hip (+ its headers) and the libq facade
   if verbose:
     print(' '.join(cmd))
   subprocess.check_call(cmd, cwd=ROOT)
