@@ -180,43 +180,104 @@ class Planner {
   int rb_cap_;
   std::vector<uint64_t> alg_override_;
 
-  // One greedy pass: take, in order, every gate that (a) commutes with all the
-  // earlier gates we had to skip and (b) fits the register tile.
-  SweepPlan build_sweep(const std::vector<GateRec> &pending, const std::vector<uint64_t> &alg,
-                        std::vector<GateRec> *rest, std::vector<uint64_t> *rest_alg) {
-    SweepPlan sp;
-    std::vector<int> regs;       // register bit positions, in order of first use
+  // One order-preserving pass over `pending` with a FIXED register-bit set: a gate
+  // is taken if (a) it commutes with every earlier gate that was skipped and (b) its
+  // target is a lane bit or one of `regmask` (diagonal gates always fit).  Returns
+  // the number of gates taken; optionally the indices taken.
+  size_t pass(const std::vector<GateRec> &pending, uint64_t regmask, size_t window,
+              std::vector<uint8_t> *taken_flags) const {
     uint64_t blocked_all = 0;    // bits a skipped gate acts densely on
     uint64_t blocked_diag = 0;   // bits a skipped gate acts diagonally on
-    std::vector<const GateRec *> taken;
-    bool any_dense = false;
-    for (size_t i = 0; i < pending.size(); ++i) {
+    size_t count = 0;
+    const size_t n = std::min(window, pending.size());
+    for (size_t i = 0; i < n; ++i) {
       const GateRec &r = pending[i];
       const bool diag = plan_diag(r.g, r.tgt);
       const uint64_t tb = (r.tgt >= 0) ? (1ull << r.tgt) : 0;
       const uint64_t dense_bits = diag ? 0 : tb;
       const uint64_t diag_bits = r.ctl_mask | (diag ? tb : 0);
       const bool can_pass = !(dense_bits & (blocked_all | blocked_diag)) && !(diag_bits & blocked_all);
-      bool fits = (int)taken.size() < kMaxSweepOps;
-      bool need_reg = false;
-      if (fits && !diag && r.tgt >= kLaneBits) {
-        if (std::find(regs.begin(), regs.end(), r.tgt) == regs.end()) {
-          if ((int)regs.size() < rb_cap_) need_reg = true;
-          else fits = false;
-        }
-      }
+      const bool fits = (count < (size_t)kMaxSweepOps) &&
+                        (diag || r.tgt < kLaneBits || ((regmask >> r.tgt) & 1ull));
       if (can_pass && fits) {
-        if (need_reg) regs.push_back(r.tgt);
-        if (!diag) any_dense = true;
-        taken.push_back(&r);
-        sp.gates++;
-        sp.alg_bytes += alg[i];
+        ++count;
+        if (taken_flags) (*taken_flags)[i] = 1;
       } else {
         blocked_all |= dense_bits;
         blocked_diag |= diag_bits;
-        rest->push_back(r);
+        // everything that can still be taken must avoid the blocked bits: once all
+        // local bits are blocked densely nothing further can pass
+      }
+    }
+    return count;
+  }
+
+  // Choose the register bits of a sweep greedily by SIMULATION: add, one at a
+  // time, the candidate bit that lets the most queued gates run in this sweep
+  // (first-come order breaks ties).  For a QFT this reproduces "next five target
+  // bits"; for layered circuits (supremacy, Grover ladders) it picks qubits whose
+  // gates unblock each other instead of the first five that happen to come up.
+  SweepPlan build_sweep(const std::vector<GateRec> &pending, const std::vector<uint64_t> &alg,
+                        std::vector<GateRec> *rest, std::vector<uint64_t> *rest_alg) {
+    SweepPlan sp;
+    const size_t window = std::min<size_t>(pending.size(), 4096);
+    std::vector<int> cand;       // dense target bits above the lanes, in order of first use
+    for (size_t i = 0; i < window; ++i) {
+      const GateRec &r = pending[i];
+      if (!plan_diag(r.g, r.tgt) && r.tgt >= kLaneBits &&
+          std::find(cand.begin(), cand.end(), r.tgt) == cand.end())
+        cand.push_back(r.tgt);
+    }
+    uint64_t regmask = 0;
+    std::vector<int> regs;
+    size_t best_total = pass(pending, 0, window, nullptr);
+    while ((int)regs.size() < rb_cap_) {
+      int best_bit = -1;
+      size_t best = best_total;
+      for (int c : cand) {
+        if ((regmask >> c) & 1ull) continue;
+        const size_t sc = pass(pending, regmask | (1ull << c), window, nullptr);
+        if (sc > best) { best = sc; best_bit = c; }
+      }
+      if (best_bit < 0) break;
+      regs.push_back(best_bit);
+      regmask |= 1ull << best_bit;
+      best_total = best;
+    }
+    std::vector<uint8_t> flags(pending.size(), 0);
+    pass(pending, regmask, pending.size(), &flags);
+    std::vector<const GateRec *> taken;
+    bool any_dense = false;
+    for (size_t i = 0; i < pending.size(); ++i) {
+      if (flags[i]) {
+        taken.push_back(&pending[i]);
+        if (!plan_diag(pending[i].g, pending[i].tgt)) any_dense = true;
+        sp.gates++;
+        sp.alg_bytes += alg[i];
+      } else {
+        rest->push_back(pending[i]);
         rest_alg->push_back(alg[i]);
       }
+    }
+    if (taken.empty()) {  // cannot happen (the first pending gate always fits some tile), but never loop forever
+      taken.push_back(&pending[0]);
+      rest->erase(rest->begin());
+      rest_alg->erase(rest_alg->begin());
+      if (!plan_diag(pending[0].g, pending[0].tgt) && pending[0].tgt >= kLaneBits) {
+        regs.assign(1, pending[0].tgt);
+        regmask = 1ull << pending[0].tgt;
+      }
+      sp.gates = 1;
+      sp.alg_bytes = alg[0];
+    }
+    // drop register bits that ended up unused (a later candidate made them moot)
+    {
+      uint64_t used = 0;
+      for (const GateRec *r : taken)
+        if (!plan_diag(r->g, r->tgt) && r->tgt >= kLaneBits) used |= 1ull << r->tgt;
+      std::vector<int> keep;
+      for (int p : regs) if ((used >> p) & 1ull) keep.push_back(p);
+      regs.swap(keep);
     }
     // Bits every taken gate requires to be 1 (only useful above the lane bits and
     // outside the register tile): fold them into the tile enumeration so that the
@@ -227,7 +288,7 @@ class Planner {
       if (plan_diag(r->g, r->tgt) && r->tgt >= 0 && is_one(r->g[0], r->g[1])) req |= 1ull << r->tgt;
       common &= req;
     }
-    uint64_t regmask = 0;
+    regmask = 0;
     for (int p : regs) regmask |= 1ull << p;
     common &= ~((1ull << kLaneBits) - 1) & ~regmask & ((1ull << nloc_) - 1);
     // keep enough free bits for the tile: need rb register bits among non-fixed bits

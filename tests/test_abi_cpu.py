@@ -105,3 +105,27 @@ def test_bitmap_roundtrip_dry(lib):
   lib.qh_logical_to_phys(h, 0b000001, ctypes.byref(o))
   assert o.value == 0b100000
   lib.qh_destroy(h)
+
+
+def test_libq_facade_header_links(tmp_path, lib):
+  """include/libq.h: every declared function resolves against libqcc_hip.so (link only)."""
+  import re
+  import subprocess
+  text = open(os.path.join(ROOT, 'include', 'libq.h')).read()
+  text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+  text = re.sub(r'//.*', '', text)
+  decl = re.findall(r'^\s*(?:void|qureg \*|float)\s*\*?(\w+)\s*\(([^)]*)\)\s*;', text, flags=re.M)
+  names = [n for n, _ in decl]
+  assert {'new_qureg', 'print_qureg', 'h', 'cu1', 'ccx', 'cv_adj', 'flush'} <= set(names) and len(names) >= 20
+  body = '\n'.join(f'  (void)&libq::{n};' for n in names)
+  # take the address of each function through a volatile sink so the linker must resolve it
+  src = tmp_path / 'link_all.cc'
+  src.write_text('#include "libq.h"\nvolatile const void* sink;\nint main() {\n' +
+                 '\n'.join(f'  sink = (const void*)&libq::{n};' for n in names if n not in ('x', 'y', 'z', 'h', 't', 'v')) +
+                 '\n  void (*f1)(int, libq::qureg*) = &libq::x; sink = (const void*)f1;'
+                 '\n  f1 = &libq::y; sink = (const void*)f1; f1 = &libq::z; sink = (const void*)f1;'
+                 '\n  f1 = &libq::h; sink = (const void*)f1; f1 = &libq::t; sink = (const void*)f1;'
+                 '\n  f1 = &libq::v; sink = (const void*)f1;\n  return 0;\n}\n')
+  libdir = os.path.join(ROOT, 'qcc_amd')
+  subprocess.check_call(['g++', '-std=c++17', str(src), '-I' + os.path.join(ROOT, 'include'), '-L' + libdir,
+                         '-lqcc_hip', '-Wl,-rpath,' + libdir, '-o', str(tmp_path / 'link_all')])

@@ -72,9 +72,14 @@ def test_commutation_rules_keep_order_where_it_matters():
   sb.apply1(gates.hadamard(), 5)
   p = _plan(n, *sb.arrays())
   assert len(p['sweeps']) == 2
-  assert p['sweeps'][0]['gates'] == 5      # H(q0..q4); H(q5), H(q6) wait
-  # CX(5->0) must come after H(5)?? no: after the skipped H(q5) -- it shares qubit 5 with it
-  assert p['sweeps'][1]['gates'] == 4
+  # the simulation-driven choice keeps qubits 0 and 5 together: H(0) H(5) CX(5->0) H(5)
+  # all run in the first sweep plus three more H; the two left-over H gates follow
+  assert p['sweeps'][0]['gates'] == 7 and p['sweeps'][1]['gates'] == 2
+  sb = workloads.StreamBuilder()           # order must survive: X then H then X on one qubit,
+  for g in (gates.pauli_x(), gates.hadamard(), gates.pauli_x()):  # interleaved with a blocker
+    sb.apply1(g, 3)
+  p = _plan(n, *sb.arrays())
+  assert len(p['sweeps']) == 1 and p['sweeps'][0]['dense_ops'] == 3
 
 
 def test_shard_bit_predicates_resolved_at_plan_time():
@@ -95,7 +100,7 @@ def test_supremacy_and_grover_streams_plan_completely():
   ops, g8 = workloads.supremacy_stream(30, 20, seed=0).arrays()
   p = _plan(30, ops, g8)
   assert sum(s['gates'] for s in p['sweeps']) + p['noop_gates'] == len(ops) == 342
-  assert len(p['sweeps']) <= 16
+  assert len(p['sweeps']) <= 10
   ops, g8 = workloads.grover_stream(10, [1, 0] * 5, iterations=1).arrays()
   p = _plan(20, ops, g8)
   assert sum(s['gates'] for s in p['sweeps']) + p['noop_gates'] == len(ops)
