@@ -46,6 +46,7 @@ inline bool plan_diag(const double g[8], int tgt) {
 constexpr int kLaneBits = 6;   // wavefront = 64 lanes
 constexpr int kMaxRegBits = 5; // 32 amplitudes (128 VGPRs of data) per lane
 constexpr int kMaxSweepOps = 1024;
+constexpr int kMaxInsertBits = 8;  // == kMaxIns of kernels_gate.hip.h (tile enumeration)
 
 enum : uint32_t { OP_DENSE_REG = 0, OP_DENSE_LANE = 1, OP_DIAG = 2 };
 // A DIAG op directly followed by an uncontrolled dense op on a LANE bit does not
@@ -294,6 +295,7 @@ class Planner {
     // keep enough free bits for the tile: need rb register bits among non-fixed bits
     int rb = std::max<int>((int)regs.size(), std::min(rb_cap_, any_dense ? rb_cap_ : 3));
     while (popc(common) > 0 && nloc_ - kLaneBits - popc(common) < rb) common &= common - 1;
+    while (popc(common) + rb > kMaxInsertBits) common &= common - 1;  // the rest stay per-op controls
     rb = std::min(rb, nloc_ - kLaneBits - popc(common));
     sp.fixed_ones = common;
     // pad the register tile with the lowest free bits (cheap, keeps runs long)

@@ -264,3 +264,28 @@ def test_error_behaviour_on_device():
     st.init_basis(0)
     st.apply1(gates.hadamard(), 0)  # still usable after errors
     assert abs(st.norm2() - 1) < 1e-15
+
+
+def test_many_common_controls_fused(oracle):
+  """5-control gates: more common control bits than the tile enumeration can fix."""
+  n = 14
+  rng = np.random.default_rng(21)
+  psi0 = _rand_state(rng, n)
+  u = _rand_unitary(rng)
+  mask = (1 << 13) | (1 << 12) | (1 << 11) | (1 << 9) | (1 << 8) | (1 << 7)
+  want = psi0.copy()
+  idx = np.arange(1 << n)
+  for tbit in (10, 2):
+    sel = ((idx & mask) == mask) & (((idx >> tbit) & 1) == 0)
+    a, b = want[idx[sel]].copy(), want[idx[sel] | (1 << tbit)].copy()
+    want[idx[sel]] = u[0, 0] * a + u[0, 1] * b
+    want[idx[sel] | (1 << tbit)] = u[1, 0] * a + u[1, 1] * b
+  ph = np.exp(0.3j)
+  want[(idx & (mask | 1 << 10)) == (mask | 1 << 10)] *= ph
+  for fusion in FUSIONS:
+    with device.DeviceState(n, 128, fusion=fusion) as st:
+      st.upload(psi0)
+      st.apply_bits(mask, 10, u)
+      st.apply_bits(mask, 2, u)
+      st.apply_bits(mask, 10, gates.u1(0.3))
+      assert np.max(np.abs(st.download() - want)) <= TOL
