@@ -14,6 +14,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -164,12 +165,17 @@ class Planner {
       alg_override_.push_back(gate_alg_bytes(r, nloc_, amp_bytes_));
     }
     std::vector<uint64_t> alg = alg_override_;
+    std::vector<uint32_t> weight(pending.size(), 1);
+    fuse_sleator_weinfurter(&pending, &alg, &weight);
+    weight_.swap(weight);
     while (!pending.empty()) {
       std::vector<GateRec> rest;
       std::vector<uint64_t> rest_alg;
-      out.sweeps.push_back(build_sweep(pending, alg, &rest, &rest_alg));
+      std::vector<uint32_t> rest_w;
+      out.sweeps.push_back(build_sweep(pending, alg, &rest, &rest_alg, &rest_w));
       pending.swap(rest);
       alg.swap(rest_alg);
+      weight_.swap(rest_w);
     }
     return out;
   }
@@ -180,6 +186,90 @@ class Planner {
   uint64_t amp_bytes_;
   int rb_cap_;
   std::vector<uint64_t> alg_override_;
+  std::vector<uint32_t> weight_;  // reference gate applications each pending record stands for
+
+  static bool near(double a, double b) { return std::fabs(a - b) <= 4e-15; }
+  static bool same_gate(const double a[8], const double b[8]) {
+    for (int i = 0; i < 8; ++i) if (!near(a[i], b[i])) return false;
+    return true;
+  }
+  static bool is_x(const double g[8]) {
+    const double x[8] = {0, 0, 1, 0, 1, 0, 0, 0};
+    for (int i = 0; i < 8; ++i) if (g[i] != x[i]) return false;
+    return true;
+  }
+  static void mat2(const double a[8], const double b[8], double out[8]) {  // out = a * b
+    for (int r = 0; r < 2; ++r)
+      for (int c = 0; c < 2; ++c) {
+        double re = 0, im = 0;
+        for (int k = 0; k < 2; ++k) {
+          const double ar = a[2 * (2 * r + k)], ai = a[2 * (2 * r + k) + 1];
+          const double br = b[2 * (2 * k + c)], bi = b[2 * (2 * k + c) + 1];
+          re += ar * br - ai * bi;
+          im += ar * bi + ai * br;
+        }
+        out[2 * (2 * r + c)] = re;
+        out[2 * (2 * r + c) + 1] = im;
+      }
+  }
+
+  // Peephole: the Sleator-Weinfurter doubly-controlled-U the reference emits for
+  // every Toffoli / ccu (src/lib/circuit.py:227-246)
+  //     C_a(V) t ; CX a->b ; C_b(V^-1) t ; CX a->b ; C_b(V) t         (V*V = U)
+  // is, exactly, ONE gate U on t controlled by a AND b.  Recognising it removes the
+  // two CX (which make b a dense target) and four of the five sweeps' worth of
+  // work; the record keeps weight 5 and the five gates' minimal-touch bytes.
+  void fuse_sleator_weinfurter(std::vector<GateRec> *pending, std::vector<uint64_t> *alg,
+                               std::vector<uint32_t> *weight) const {
+    std::vector<GateRec> out;
+    std::vector<uint64_t> oalg;
+    std::vector<uint32_t> ow;
+    const std::vector<GateRec> &q = *pending;
+    size_t i = 0;
+    while (i < q.size()) {
+      bool fused = false;
+      if (i + 4 < q.size()) {
+        const GateRec &g1 = q[i], &g2 = q[i + 1], &g3 = q[i + 2], &g4 = q[i + 3], &g5 = q[i + 4];
+        const int t = g1.tgt, b = g2.tgt;
+        if (t >= 0 && b >= 0 && b != t && g3.tgt == t && g5.tgt == t && g4.tgt == b && is_x(g2.g) &&
+            is_x(g4.g) && g2.ctl_mask == g4.ctl_mask && g1.ctl_mask == g2.ctl_mask &&
+            g3.ctl_mask == g5.ctl_mask && !((g1.ctl_mask >> b) & 1ull) && ((g3.ctl_mask >> b) & 1ull)) {
+          const uint64_t common = g3.ctl_mask & ~(1ull << b);
+          const uint64_t a_mask = g1.ctl_mask & ~common;
+          if ((g1.ctl_mask & common) == common && popc(a_mask) == 1 && same_gate(g1.g, g5.g)) {
+            double prod[8];
+            mat2(g3.g, g1.g, prod);  // V^-1 * V must be the identity
+            const double id[8] = {1, 0, 0, 0, 0, 0, 1, 0};
+            if (same_gate(prod, id)) {
+              GateRec r = g1;
+              r.ctl_mask = g1.ctl_mask | (1ull << b);
+              mat2(g1.g, g1.g, r.g);
+              // snap entries that are zero/one up to rounding, so X stays a permutation
+              for (int k = 0; k < 8; ++k) {
+                if (std::fabs(r.g[k]) < 4e-16) r.g[k] = 0.0;
+                if (near(r.g[k], 1.0)) r.g[k] = 1.0;
+                if (near(r.g[k], -1.0)) r.g[k] = -1.0;
+              }
+              out.push_back(r);
+              oalg.push_back((*alg)[i] + (*alg)[i + 1] + (*alg)[i + 2] + (*alg)[i + 3] + (*alg)[i + 4]);
+              ow.push_back(5);
+              i += 5;
+              fused = true;
+            }
+          }
+        }
+      }
+      if (!fused) {
+        out.push_back(q[i]);
+        oalg.push_back((*alg)[i]);
+        ow.push_back((*weight)[i]);
+        ++i;
+      }
+    }
+    pending->swap(out);
+    alg->swap(oalg);
+    weight->swap(ow);
+  }
 
   // One order-preserving pass over `pending` with a FIXED register-bit set: a gate
   // is taken if (a) it commutes with every earlier gate that was skipped and (b) its
@@ -219,7 +309,8 @@ class Planner {
   // bits"; for layered circuits (supremacy, Grover ladders) it picks qubits whose
   // gates unblock each other instead of the first five that happen to come up.
   SweepPlan build_sweep(const std::vector<GateRec> &pending, const std::vector<uint64_t> &alg,
-                        std::vector<GateRec> *rest, std::vector<uint64_t> *rest_alg) {
+                        std::vector<GateRec> *rest, std::vector<uint64_t> *rest_alg,
+                        std::vector<uint32_t> *rest_w) {
     SweepPlan sp;
     const size_t window = std::min<size_t>(pending.size(), 4096);
     std::vector<int> cand;       // dense target bits above the lanes, in order of first use
@@ -253,22 +344,24 @@ class Planner {
       if (flags[i]) {
         taken.push_back(&pending[i]);
         if (!plan_diag(pending[i].g, pending[i].tgt)) any_dense = true;
-        sp.gates++;
+        sp.gates += weight_[i];
         sp.alg_bytes += alg[i];
       } else {
         rest->push_back(pending[i]);
         rest_alg->push_back(alg[i]);
+        rest_w->push_back(weight_[i]);
       }
     }
     if (taken.empty()) {  // cannot happen (the first pending gate always fits some tile), but never loop forever
       taken.push_back(&pending[0]);
       rest->erase(rest->begin());
       rest_alg->erase(rest_alg->begin());
+      rest_w->erase(rest_w->begin());
       if (!plan_diag(pending[0].g, pending[0].tgt) && pending[0].tgt >= kLaneBits) {
         regs.assign(1, pending[0].tgt);
         regmask = 1ull << pending[0].tgt;
       }
-      sp.gates = 1;
+      sp.gates = weight_[0];
       sp.alg_bytes = alg[0];
     }
     // drop register bits that ended up unused (a later candidate made them moot)
