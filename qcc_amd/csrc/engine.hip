@@ -113,54 +113,56 @@ int gate_u() { static int v = env_int("QH_GATE_U", 1); return v; }
 bool gate_nt() { static int v = env_int("QH_GATE_NT", 1); return v != 0; }
 
 template <typename R, int U, bool NT>
-void launch_pair_u(qh_state_s *h, uint64_t nwork, int p, const qh::BitIns &ins, const double g[8]) {
+void launch_pair_u(qh_state_s *h, uint64_t nwork, int p, const qh::BitIns &ins, const double g[8],
+                   uint32_t lowpred) {
   using A = typename qh::AmpT<R>::type;
   const unsigned grid = pick_grid(nwork, 256 * U);
   if (nwork % (256 * U) == 0)
     hipLaunchKernelGGL((qh::k_pair<R, U, false, NT>), dim3(grid), dim3(256), 0, h->stream,
-                       (A *)h->d_psi, nwork, p, ins, to_gate<R>(g));
+                       (A *)h->d_psi, nwork, p, ins, to_gate<R>(g), lowpred);
   else
     hipLaunchKernelGGL((qh::k_pair<R, U, true, NT>), dim3(grid), dim3(256), 0, h->stream,
-                       (A *)h->d_psi, nwork, p, ins, to_gate<R>(g));
+                       (A *)h->d_psi, nwork, p, ins, to_gate<R>(g), lowpred);
 }
 template <typename R>
-void launch_pair(qh_state_s *h, uint64_t nwork, int p, const qh::BitIns &ins, const double g[8]) {
+void launch_pair(qh_state_s *h, uint64_t nwork, int p, const qh::BitIns &ins, const double g[8],
+                 uint32_t lowpred) {
   const int u = gate_u();
   if (gate_nt()) {
-    if (u >= 4) launch_pair_u<R, 4, true>(h, nwork, p, ins, g);
-    else if (u == 2) launch_pair_u<R, 2, true>(h, nwork, p, ins, g);
-    else launch_pair_u<R, 1, true>(h, nwork, p, ins, g);
+    if (u >= 4) launch_pair_u<R, 4, true>(h, nwork, p, ins, g, lowpred);
+    else if (u == 2) launch_pair_u<R, 2, true>(h, nwork, p, ins, g, lowpred);
+    else launch_pair_u<R, 1, true>(h, nwork, p, ins, g, lowpred);
   } else {
-    if (u >= 4) launch_pair_u<R, 4, false>(h, nwork, p, ins, g);
-    else if (u == 2) launch_pair_u<R, 2, false>(h, nwork, p, ins, g);
-    else launch_pair_u<R, 1, false>(h, nwork, p, ins, g);
+    if (u >= 4) launch_pair_u<R, 4, false>(h, nwork, p, ins, g, lowpred);
+    else if (u == 2) launch_pair_u<R, 2, false>(h, nwork, p, ins, g, lowpred);
+    else launch_pair_u<R, 1, false>(h, nwork, p, ins, g, lowpred);
   }
 }
 
 template <typename R, int U, bool NT>
 void launch_diag_u(qh_state_s *h, uint64_t nwork, int sel, const qh::BitIns &ins, double f0r, double f0i,
-                   double f1r, double f1i) {
+                   double f1r, double f1i, uint32_t lowpred) {
   using A = typename qh::AmpT<R>::type;
   const unsigned grid = pick_grid(nwork, 256 * U);
   if (nwork % (256 * U) == 0)
     hipLaunchKernelGGL((qh::k_diag<R, U, false, NT>), dim3(grid), dim3(256), 0, h->stream,
-                       (A *)h->d_psi, nwork, sel, ins, (R)f0r, (R)f0i, (R)f1r, (R)f1i);
+                       (A *)h->d_psi, nwork, sel, ins, (R)f0r, (R)f0i, (R)f1r, (R)f1i, lowpred);
   else
     hipLaunchKernelGGL((qh::k_diag<R, U, true, NT>), dim3(grid), dim3(256), 0, h->stream,
-                       (A *)h->d_psi, nwork, sel, ins, (R)f0r, (R)f0i, (R)f1r, (R)f1i);
+                       (A *)h->d_psi, nwork, sel, ins, (R)f0r, (R)f0i, (R)f1r, (R)f1i, lowpred);
 }
 template <typename R>
 void launch_diag(qh_state_s *h, uint64_t nwork, int sel, const qh::BitIns &ins, double f0r, double f0i,
-                 double f1r, double f1i) {
+                 double f1r, double f1i, uint32_t lowpred = 0) {
   const int u = gate_u() * 2;  // a diagonal work item is one amplitude, a pair item two
   if (gate_nt()) {
-    if (u >= 4) launch_diag_u<R, 4, true>(h, nwork, sel, ins, f0r, f0i, f1r, f1i);
-    else if (u == 2) launch_diag_u<R, 2, true>(h, nwork, sel, ins, f0r, f0i, f1r, f1i);
-    else launch_diag_u<R, 1, true>(h, nwork, sel, ins, f0r, f0i, f1r, f1i);
+    if (u >= 4) launch_diag_u<R, 4, true>(h, nwork, sel, ins, f0r, f0i, f1r, f1i, lowpred);
+    else if (u == 2) launch_diag_u<R, 2, true>(h, nwork, sel, ins, f0r, f0i, f1r, f1i, lowpred);
+    else launch_diag_u<R, 1, true>(h, nwork, sel, ins, f0r, f0i, f1r, f1i, lowpred);
   } else {
-    if (u >= 4) launch_diag_u<R, 4, false>(h, nwork, sel, ins, f0r, f0i, f1r, f1i);
-    else if (u == 2) launch_diag_u<R, 2, false>(h, nwork, sel, ins, f0r, f0i, f1r, f1i);
-    else launch_diag_u<R, 1, false>(h, nwork, sel, ins, f0r, f0i, f1r, f1i);
+    if (u >= 4) launch_diag_u<R, 4, false>(h, nwork, sel, ins, f0r, f0i, f1r, f1i, lowpred);
+    else if (u == 2) launch_diag_u<R, 2, false>(h, nwork, sel, ins, f0r, f0i, f1r, f1i, lowpred);
+    else launch_diag_u<R, 1, false>(h, nwork, sel, ins, f0r, f0i, f1r, f1i, lowpred);
   }
 }
 
@@ -171,7 +173,12 @@ int launch_single(qh_state_s *h, const qh::GateRec &r) {
     h->stats.gates_noop++;
     return QH_OK;
   }
-  const uint64_t cm = r.ctl_mask & h->local_mask();
+  const uint64_t cm_all = r.ctl_mask & h->local_mask();
+  // bits 0,1 are never skipped in the enumeration (same 64-byte half line): predicate
+  const uint64_t kLow = (h->nloc > 2) ? 3ull : 0ull;
+  uint32_t lowpred = (uint32_t)(cm_all & kLow);
+  const uint64_t cm = cm_all & ~kLow;
+  const int nc_all = __builtin_popcountll(cm_all);
   const int nc = __builtin_popcountll(cm);
   if (nc + 1 > qh::kMaxIns) return fail(QH_ERR_ARG, "too many local control bits (%d)", nc);
   const double *g = r.g;
@@ -192,11 +199,11 @@ int launch_single(qh_state_s *h, const qh::GateRec &r) {
     const uint64_t nwork = 1ull << (h->nloc - nc);
     if (!h->dry) {
       const qh::BitIns ins = make_ins(cm, -1);
-      if (h->bw == 128) launch_diag<double>(h, nwork, -1, ins, 1, 0, fr, fi);
-      else launch_diag<float>(h, nwork, -1, ins, 1, 0, fr, fi);
+      if (h->bw == 128) launch_diag<double>(h, nwork, -1, ins, 1, 0, fr, fi, lowpred);
+      else launch_diag<float>(h, nwork, -1, ins, 1, 0, fr, fi, lowpred);
     }
     h->stats.kernels_launched++;
-    h->stats.bytes_algorithmic += nwork * ab * 2;
+    h->stats.bytes_algorithmic += (1ull << (h->nloc - nc_all)) * ab * 2;
     h->stats.bytes_swept += nwork * ab * 2;
     return QH_OK;
   }
@@ -207,22 +214,24 @@ int launch_single(qh_state_s *h, const qh::GateRec &r) {
       return QH_OK;  // identity
     }
     if (one_sided) {
-      const uint64_t nwork = 1ull << (h->nloc - nc - 1);
+      const bool tgt_low = ((kLow >> r.tgt) & 1ull) != 0;   // target itself inside the half line
+      if (tgt_low) lowpred |= 1u << r.tgt;
+      const uint64_t nwork = 1ull << (h->nloc - nc - (tgt_low ? 0 : 1));
       if (!h->dry) {
-        const qh::BitIns ins = make_ins(cm | (1ull << r.tgt), -1);
-        if (h->bw == 128) launch_diag<double>(h, nwork, -1, ins, 1, 0, g[6], g[7]);
-        else launch_diag<float>(h, nwork, -1, ins, 1, 0, g[6], g[7]);
+        const qh::BitIns ins = make_ins(tgt_low ? cm : (cm | (1ull << r.tgt)), -1);
+        if (h->bw == 128) launch_diag<double>(h, nwork, -1, ins, 1, 0, g[6], g[7], lowpred);
+        else launch_diag<float>(h, nwork, -1, ins, 1, 0, g[6], g[7], lowpred);
       }
-      h->stats.bytes_algorithmic += nwork * ab * 2;
+      h->stats.bytes_algorithmic += (1ull << (h->nloc - nc_all - 1)) * ab * 2;
       h->stats.bytes_swept += nwork * ab * 2;
     } else {
       const uint64_t nwork = 1ull << (h->nloc - nc);
       if (!h->dry) {
         const qh::BitIns ins = make_ins(cm, -1);
-        if (h->bw == 128) launch_diag<double>(h, nwork, r.tgt, ins, g[0], g[1], g[6], g[7]);
-        else launch_diag<float>(h, nwork, r.tgt, ins, g[0], g[1], g[6], g[7]);
+        if (h->bw == 128) launch_diag<double>(h, nwork, r.tgt, ins, g[0], g[1], g[6], g[7], lowpred);
+        else launch_diag<float>(h, nwork, r.tgt, ins, g[0], g[1], g[6], g[7], lowpred);
       }
-      h->stats.bytes_algorithmic += nwork * ab * 2;
+      h->stats.bytes_algorithmic += (1ull << (h->nloc - nc_all)) * ab * 2;
       h->stats.bytes_swept += nwork * ab * 2;
     }
     h->stats.kernels_launched++;
@@ -231,11 +240,11 @@ int launch_single(qh_state_s *h, const qh::GateRec &r) {
   const uint64_t nwork = 1ull << (h->nloc - nc - 1);
   if (!h->dry) {
     const qh::BitIns ins = make_ins(cm, r.tgt);
-    if (h->bw == 128) launch_pair<double>(h, nwork, r.tgt, ins, g);
-    else launch_pair<float>(h, nwork, r.tgt, ins, g);
+    if (h->bw == 128) launch_pair<double>(h, nwork, r.tgt, ins, g, lowpred);
+    else launch_pair<float>(h, nwork, r.tgt, ins, g, lowpred);
   }
   h->stats.kernels_launched++;
-  h->stats.bytes_algorithmic += nwork * 2 * ab * 2;
+  h->stats.bytes_algorithmic += (1ull << (h->nloc - nc_all - 1)) * 2 * ab * 2;
   h->stats.bytes_swept += nwork * 2 * ab * 2;
   return QH_OK;
 }
