@@ -206,6 +206,31 @@ class ShardedState:
     self.gates += len(cq)
 
   # ------------------------------------------------------------------ the exchange step
+  def _swap_chunks(self, pairs):
+    """pairs: [(peer, view)] -- send `view` to peer and replace it by what peer sends.
+
+    NCCL/RCCL moves HBM views directly; with the gloo backend and a GPU-resident
+    shard (used to test this layer with two processes on ONE GPU) the chunks are
+    staged through host memory."""
+    torch, dist = self.torch, self.dist
+    via_host = self.buf.is_cuda and dist.get_backend() == 'gloo'
+    ops, recv = [], []
+    for slot, (peer, view) in enumerate(pairs):
+      n = view.numel()
+      if via_host:
+        src = view.cpu()
+        dst = torch.empty_like(src)
+      else:
+        src = view
+        dst = self._staging[self._stage_stride * slot: self._stage_stride * slot + n]
+      ops.append(dist.P2POp(dist.isend, src, peer))
+      ops.append(dist.P2POp(dist.irecv, dst, peer))
+      recv.append((view, dst))
+    for req in dist.batch_isend_irecv(ops):
+      req.wait()
+    for view, dst in recv:
+      view.copy_(dst)
+
   def _exchange(self, shard_phys_bit):
     if self.exchange_mode == 'alltoall' and self.g > 1:
       self._exchange_all()
@@ -229,20 +254,11 @@ class ShardedState:
     need = 2 * chunk * (P - 1)
     if self._staging is None or self._staging.numel() < need:
       self._staging = torch.empty(need, dtype=self.buf.dtype, device=self.buf.device)
+    self._stage_stride = 2 * chunk
     peers = [j for j in range(P) if j != r]
     for off in range(0, blk, chunk):
       n = min(chunk, blk - off)
-      ops, pairs = [], []
-      for slot, j in enumerate(peers):
-        view = self.buf[2 * (j * blk + off): 2 * (j * blk + off + n)]
-        stage = self._staging[2 * chunk * slot: 2 * chunk * slot + 2 * n]
-        ops.append(dist.P2POp(dist.isend, view, j))
-        ops.append(dist.P2POp(dist.irecv, stage, j))
-        pairs.append((view, stage))
-      for req in dist.batch_isend_irecv(ops):
-        req.wait()
-      for view, stage in pairs:
-        view.copy_(stage)
+      self._swap_chunks([(j, self.buf[2 * (j * blk + off): 2 * (j * blk + off + n)]) for j in peers])
     if self.buf.is_cuda:
       torch.cuda.synchronize()
     for k in range(g):                               # shard bit k <-> local bit nloc-g+k
@@ -262,17 +278,12 @@ class ShardedState:
     half = 1 << top                                   # amplitudes
     start = (1 - mybit) * half                        # the half whose top bit != my shard bit
     self.eng.sync()                                   # kernels done before RCCL touches the shard
-    if self._staging is None:
+    if self._staging is None or self._staging.numel() < 2 * self.chunk:
       self._staging = torch.empty(2 * self.chunk, dtype=self.buf.dtype, device=self.buf.device)
+    self._stage_stride = 2 * self.chunk
     for off in range(0, half, self.chunk):
       n = min(self.chunk, half - off)
-      view = self.buf[2 * (start + off): 2 * (start + off + n)]
-      stage = self._staging[: 2 * n]
-      reqs = dist.batch_isend_irecv([dist.P2POp(dist.isend, view, partner),
-                                     dist.P2POp(dist.irecv, stage, partner)])
-      for r in reqs:
-        r.wait()
-      view.copy_(stage)
+      self._swap_chunks([(partner, self.buf[2 * (start + off): 2 * (start + off + n)])])
     if self.buf.is_cuda:
       torch.cuda.synchronize()
     # bookkeeping: the two logical bits trade physical homes
@@ -289,8 +300,12 @@ class ShardedState:
   def sync(self):
     self.eng.sync()
 
+  def _red_device(self):
+    """Device for the tiny reduction tensors: the shard's device under RCCL, host under gloo."""
+    return 'cpu' if self.dist.get_backend() == 'gloo' else self.buf.device
+
   def norm2_global(self):
-    t = self.torch.tensor([self.eng.norm2()], dtype=self.torch.float64, device=self.buf.device)
+    t = self.torch.tensor([self.eng.norm2()], dtype=self.torch.float64, device=self._red_device())
     self.dist.all_reduce(t)
     return float(t.item())
 
@@ -298,10 +313,10 @@ class ShardedState:
     """(logical index, probability) of the likeliest basis state."""
     li, p = self.eng.argmax()
     phys = (self.rank << self.nloc) | li
-    t = self.torch.tensor([p, float(self.rank)], dtype=self.torch.float64, device=self.buf.device)
+    t = self.torch.tensor([p, float(self.rank)], dtype=self.torch.float64, device=self._red_device())
     allp = [self.torch.zeros_like(t) for _ in range(self.world)]
     self.dist.all_gather(allp, t)
-    idx = self.torch.tensor([phys], dtype=self.torch.int64, device=self.buf.device)
+    idx = self.torch.tensor([phys], dtype=self.torch.int64, device=self._red_device())
     alli = [self.torch.zeros_like(idx) for _ in range(self.world)]
     self.dist.all_gather(alli, idx)
     best = max(range(self.world), key=lambda r: (float(allp[r][0]), -r))
@@ -318,9 +333,11 @@ class ShardedState:
     """Whole state in LOGICAL order on every rank (tests / small n only)."""
     torch = self.torch
     self.eng.sync()
+    if self.buf.is_cuda:
+      torch.cuda.synchronize()
     mine = self.buf.detach().to('cpu') if self.buf.is_cuda else self.buf
     parts = [torch.zeros_like(mine) for _ in range(self.world)]
-    if self.buf.is_cuda:
+    if self.buf.is_cuda and self.dist.get_backend() != 'gloo':
       cu = [torch.zeros_like(self.buf) for _ in range(self.world)]
       self.dist.all_gather(cu, self.buf)
       parts = [c.cpu() for c in cu]
