@@ -86,6 +86,9 @@ class ShardedState:
     self.chunk = min(int(chunk_amps), 1 << (self.nloc - 1))
     assert exchange in ('alltoall', 'pairwise')
     self.exchange_mode = exchange if self.nloc >= 2 * self.g else 'pairwise'
+    self.min_evict_bit = max(2, min(20, self.nloc - 3 * self.g))
+    self._last_use = {}      # physical bit -> sequence number of its last use as a dense target
+    self._seq = 0
     self._staging = None
     self.exchanges = 0
     self.exchanged_bytes = 0
@@ -133,6 +136,9 @@ class ShardedState:
     if pt >= self.nloc and not diag:
       self._exchange(pt)                      # collective: before any rank-dependent skip
       pt = self.perm[tgt_bit]
+    if not diag:
+      self._seq += 1
+      self._last_use[pt] = self._seq
     pm = self._phys_mask(ctl_mask)
     hi = pm >> self.nloc
     if (self.rank & hi) != hi:
@@ -180,7 +186,8 @@ class ShardedState:
       pt = perm[tb]
       if pt >= nloc:
         if not diag[k]:
-          self._exchange(pt)
+          evict = self._evict_group(tbits, diag, k) if self.exchange_mode == 'alltoall' else None
+          self._exchange(pt, evict)
           perm = self.perm
           pt = perm[tb]
         else:                                  # diagonal on a shard bit: general path
@@ -189,6 +196,9 @@ class ShardedState:
           cmask = 0 if cq[k] == NO_CTL else 1 << (n - 1 - cq[k])
           self.apply_bits(cmask, tb, gc[k])
           continue
+      if not diag[k]:
+        self._seq += 1
+        self._last_use[pt] = self._seq
       if cq[k] == NO_CTL:
         cm = 0
       else:
@@ -231,42 +241,84 @@ class ShardedState:
     for view, dst in recv:
       view.copy_(dst)
 
-  def _exchange(self, shard_phys_bit):
-    if self.exchange_mode == 'alltoall' and self.g > 1:
-      self._exchange_all()
+  def _exchange(self, shard_phys_bit, base=None):
+    if self.exchange_mode == 'alltoall':
+      self._exchange_all(base)
     else:
       self._exchange_pair(shard_phys_bit)
 
-  def _exchange_all(self):
-    """Swap ALL g shard bits with the top g local bits in one step.
+  def _evict_group(self, tbits, diag, k):
+    """Which g consecutive local bits to hand to the shard index when gate k of a
+    known stream forces an exchange: the aligned group (not below bit
+    `min_evict_bit`, so runs stay >= 16 MiB at benchmark sizes) whose qubits are
+    needed as a dense TARGET farthest in the future (Belady).  A QFT repeated in a
+    loop then pays ONE exchange per QFT instead of two."""
+    g, nloc = self.g, self.nloc
+    lo = min(self.min_evict_bit, nloc - g)
+    groups = [b for b in range(nloc - g, lo - 1, -g)]
+    if len(groups) <= 1:
+      return nloc - g
+    where = {}                                       # physical bit -> group base
+    for b in groups:
+      for j in range(g):
+        where[b + j] = b
+    nxt = {b: None for b in groups}
+    pending = len(groups)
+    horizon = min(len(tbits), k + 1 + 4096)
+    for m in range(k + 1, horizon):
+      if diag[m]:
+        continue
+      gb = where.get(self.perm[tbits[m]])
+      if gb is not None and nxt[gb] is None:
+        nxt[gb] = m
+        pending -= 1
+        if pending == 0:
+          break
+    never = [b for b in groups if nxt[b] is None]
+    if never:
+      # no known future use: assume the access pattern repeats (loops over the same
+      # circuit) and give away the group used MOST recently -- it is needed last
+      return max(never, key=lambda b: max(self._last_use.get(b + j, -1) for j in range(g)))
+    return max(groups, key=lambda b: nxt[b])
 
-    The shard is P blocks (selected by its top g local bits); block j goes to
-    rank j and lands there as block `rank`; block `rank` stays.  Every rank talks
-    to its P-1 peers at once (one grouped send/recv per peer and chunk), so all
-    xGMI links of the GPU carry 1/P of the shard each -- instead of g successive
+  def _exchange_all(self, base=None):
+    """Swap ALL g shard bits with g consecutive local bits [base, base+g) in one step
+    (default: the top g local bits).
+
+    The shard is P blocks selected by those g local bits; block j goes to rank j
+    and lands there as block `rank`; block `rank` stays.  Every rank talks to its
+    P-1 peers at once (one grouped send/recv per peer and chunk), so all xGMI
+    links of the GPU carry 1/P of the shard each -- instead of g successive
     pairwise exchanges of half a shard over a single link.  In place: chunks go
-    through a (P-1) x chunk staging buffer."""
-    torch, dist = self.torch, self.dist
+    through a (P-1) x chunk staging buffer.  With base below the top, a block is
+    2^(nloc-base-g) runs of 2^base contiguous amplitudes."""
+    torch = self.torch
     P, g, r = self.world, self.g, self.rank
-    blk = 1 << (self.nloc - g)                       # amplitudes per block
-    chunk = min(self.chunk, blk)
+    base = self.nloc - g if base is None else int(base)
+    assert 0 <= base <= self.nloc - g
+    run = 1 << base                                  # contiguous amplitudes per run
+    nruns = 1 << (self.nloc - base - g)
+    stride = run << g
+    chunk = min(self.chunk, run)
     self.eng.sync()
     need = 2 * chunk * (P - 1)
     if self._staging is None or self._staging.numel() < need:
       self._staging = torch.empty(need, dtype=self.buf.dtype, device=self.buf.device)
     self._stage_stride = 2 * chunk
     peers = [j for j in range(P) if j != r]
-    for off in range(0, blk, chunk):
-      n = min(chunk, blk - off)
-      self._swap_chunks([(j, self.buf[2 * (j * blk + off): 2 * (j * blk + off + n)]) for j in peers])
+    for hi in range(nruns):
+      for off in range(0, run, chunk):
+        n = min(chunk, run - off)
+        self._swap_chunks([(j, self.buf[2 * (hi * stride + j * run + off): 2 * (hi * stride + j * run + off + n)])
+                           for j in peers])
     if self.buf.is_cuda:
       torch.cuda.synchronize()
-    for k in range(g):                               # shard bit k <-> local bit nloc-g+k
-      a_phys, b_phys = self.nloc + k, self.nloc - g + k
+    for k in range(g):                               # shard bit k <-> local bit base+k
+      a_phys, b_phys = self.nloc + k, base + k
       la, lb = self.perm.index(a_phys), self.perm.index(b_phys)
       self.perm[la], self.perm[lb] = b_phys, a_phys
     self.exchanges += 1
-    self.exchanged_bytes += (P - 1) * blk * 16
+    self.exchanged_bytes += (P - 1) * (1 << (self.nloc - g)) * 16
 
   def _exchange_pair(self, shard_phys_bit):
     """Swap the data of physical shard bit with the top local bit (pairwise, in place)."""

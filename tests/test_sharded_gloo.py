@@ -99,6 +99,49 @@ def test_qft_needs_exactly_g_exchanges(tmp_path):
   assert np.max(np.abs(res['psi'] - want)) < 1e-12
 
 
+@pytest.mark.parametrize('reps', [4, 5])
+def test_repeated_qft_one_exchange_per_step(tmp_path, reps):
+  """Belady / MRU choice of the evicted bit group: steady state = ONE exchange per QFT."""
+  n, world = 10, 4
+  port = _free_port()
+  mp.spawn(_qft_repeat, args=(world, port, n, reps, str(tmp_path)), nprocs=world, join=True)
+  res = np.load(tmp_path / 'rep.npz')
+  assert int(res['exchanges']) <= reps + 1, int(res['exchanges'])
+  assert np.max(np.abs(res['psi'] - res['want'])) < 1e-12
+
+
+def _qft_repeat(rank, world, port, n, reps, out_dir):
+  os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                    LOCAL_RANK=str(rank))
+  import torch.distributed as dist
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  from qcc_amd import sharded
+  from tests import fake_device, oracle_lib
+
+  def factory(nloc):
+    e = fake_device.NumpyShardEngine(nloc)
+    return e, e.buf
+  st = sharded.ShardedState(n, engine_factory=factory, chunk_amps=16)
+  st.min_evict_bit = 2
+  st.init_basis(0b1100101)
+  ops, g8 = workloads.qft_stream(range(n)).arrays()
+  if reps % 2:                           # odd: one call, the router sees the whole stream (Belady)
+    st.run_stream(np.concatenate([ops] * reps), np.concatenate([g8] * reps))
+  else:                                  # even: one call per QFT as bench.py does (MRU fallback)
+    for _ in range(reps):
+      st.run_stream(ops, g8)
+  ops = np.concatenate([ops] * reps)
+  g8 = np.concatenate([g8] * reps)
+  full = st.gather_logical()
+  if rank == 0:
+    want = np.zeros(1 << n, dtype=np.complex128)
+    want[0b1100101] = 1
+    oracle_lib.load().run_stream(want, n, ops, g8)
+    np.savez(os.path.join(out_dir, 'rep.npz'), psi=full, want=want, exchanges=st.exchanges)
+  dist.barrier()
+  dist.destroy_process_group()
+
+
 def _qft_only(rank, world, port, n, out_dir):
   os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                     LOCAL_RANK=str(rank))
