@@ -454,7 +454,9 @@ class Planner {
         if (r->tgt < kLaneBits) { op.kind = OP_DENSE_LANE; op.tb = r->tgt; }
         else { op.kind = OP_DENSE_REG; op.tb = reg_index(*sp, r->tgt); }
         if (r->g[1] == 0.0 && r->g[3] == 0.0 && r->g[5] == 0.0 && r->g[7] == 0.0) op.flags |= OPF_REAL;
-        if (op.kind == OP_DENSE_LANE && op.cm_thread == 0 && op.cm_reg == 0 && !sp->ops.empty() &&
+        // (for a REAL gate folding would turn its 4-op real path into the 9-op complex
+        // one: no gain over applying c to the slots, so only complex gates fold)
+        if (!(op.flags & OPF_REAL) && op.kind == OP_DENSE_LANE && op.cm_thread == 0 && op.cm_reg == 0 && !sp->ops.empty() &&
             sp->ops.back().kind == OP_DIAG && sp->ops.size() == n_ops_after_flush) {
           sp->ops.back().flags |= OPF_DEFER_C;
           op.flags |= OPF_USE_C;
