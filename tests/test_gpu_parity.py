@@ -289,3 +289,47 @@ def test_many_common_controls_fused(oracle):
       st.apply_bits(mask, 2, u)
       st.apply_bits(mask, 10, gates.u1(0.3))
       assert np.max(np.abs(st.download() - want)) <= TOL
+
+
+@pytest.mark.parametrize('n,ngates,seed', [(8, 120, 0), (11, 250, 1), (14, 300, 2), (17, 200, 3)])
+def test_complex64_fused_streams_vs_oracle(oracle, n, ngates, seed):
+  """complex64 states through the fused sweeps (sweep_island_f32_*): reference default width."""
+  rng = np.random.default_rng(seed + 50)
+  pool = _gate_pool(rng)
+  ops, gs = [], []
+  for _ in range(ngates):
+    t = int(rng.integers(n))
+    g = pool[int(rng.integers(len(pool)))]
+    if rng.random() < 0.55:
+      ops.append((int((t + 1 + rng.integers(n - 1)) % n), t))
+    else:
+      ops.append((NO_CTL, t))
+    gs.append(np.asarray(g, dtype=np.complex128).reshape(4))
+  ops = np.array(ops, dtype=np.int32)
+  g8 = np.array(gs).view(np.float64).reshape(-1, 8)
+  psi0 = _rand_state(rng, n, np.complex64)
+  want = psi0.copy()
+  for (c, t), g in zip(ops, gs):
+    if c == NO_CTL:
+      oracle.apply1(want, g.astype(np.complex64), n, int(t))
+    else:
+      oracle.applyc(want, g.astype(np.complex64), n, int(c), int(t))
+  with device.DeviceState(n, 64, fusion=native.QH_FUSE_SWEEP) as st:
+    st.upload(psi0)
+    st.run_stream(ops, g8)
+    got = st.download()
+    s = st.stats()
+  assert s['sweeps'] >= 1                      # really the fused path
+  assert got.dtype == np.complex64
+  assert np.max(np.abs(got - want)) <= 3e-5    # float32 accumulation over hundreds of gates
+
+
+def test_complex64_qft_fused_analytic():
+  n, x = 20, 0xBEEF5
+  ops, g8 = workloads.qft_stream(range(n)).arrays()
+  with device.DeviceState(n, 64, fusion=native.QH_FUSE_SWEEP) as st:
+    st.init_basis(x)
+    st.run_stream(ops, g8)
+    got = st.download()
+  want = workloads.qft_analytic(n, x, np.arange(1 << n))
+  assert np.max(np.abs(got - want)) < 2e-6 * 5

@@ -14,8 +14,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from qcc_amd import device, gates, native, workloads  # noqa: E402
 
 
-def timed_stream(n, ops, g8, init, fusion, reps):
-  with device.DeviceState(n, 128, fusion=fusion) as st:
+def timed_stream(n, ops, g8, init, fusion, reps, bw=128):
+  with device.DeviceState(n, bw, fusion=fusion) as st:
     st.init_basis(init)
     st.run_stream(ops, g8); st.flush(); st.sync()   # warm-up (also makes the state dense)
     st.reset_stats()
@@ -24,8 +24,8 @@ def timed_stream(n, ops, g8, init, fusion, reps):
       st.run_stream(ops, g8); st.flush()
     ms = st.timer_end() / reps
     s = st.stats()
-  S = 16 * 2 ** n
-  return {'qubits': n, 'gates': len(ops), 'fusion': fusion, 'ms': round(ms, 3), 'gate_applies_per_s': round(len(ops) / ms * 1e3, 1),
+  S = (16 if bw == 128 else 8) * 2 ** n
+  return {'qubits': n, 'bit_width': bw, 'gates': len(ops), 'fusion': fusion, 'ms': round(ms, 3), 'gate_applies_per_s': round(len(ops) / ms * 1e3, 1),
           'launches': s['kernels_launched'] // reps, 'swept_over_S': round(s['bytes_swept'] / reps / S, 2),
           'algorithmic_over_S': round(s['bytes_algorithmic'] / reps / S, 2),
           'hbm_GBps_swept': round(s['bytes_swept'] / reps / ms / 1e6, 1)}
@@ -35,6 +35,9 @@ out = {}
 ops, g8 = workloads.supremacy_stream(30, 20, seed=0).arrays()
 out['config3_supremacy30_fused'] = timed_stream(30, ops, g8, 0, native.QH_FUSE_SWEEP, 3)
 out['config3_supremacy30_unfused'] = timed_stream(30, ops, g8, 0, native.QH_FUSE_OFF, 1)
+ops, g8 = workloads.qft_stream(range(30)).arrays()
+out['qft30_complex64_fused'] = timed_stream(30, ops, g8, 5, native.QH_FUSE_SWEEP, 3, bw=64)
+out['qft31_complex64_fused'] = timed_stream(31, *workloads.qft_stream(range(31)).arrays(), 5, native.QH_FUSE_SWEEP, 3, bw=64)
 if '--no34' not in sys.argv:
   nb = 17
   ops, g8 = workloads.grover_stream(nb, [1, 0] * 8 + [1], iterations=1).arrays()

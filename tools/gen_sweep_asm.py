@@ -9,7 +9,12 @@ hipcc's register allocator copies the whole tile at every op-kind branch (2x the
 VGPRs, spills at RB=5, one v_mov per amplitude per op), so the loop is written
 by hand: every op updates the tile in place.
 
-Register map (island-private, declared as clobbers to the compiler):
+Two element types: complex128 (sweep_island_rb*.inc, a real number = a VGPR
+pair) and complex64 (sweep_island_f32_rb*.inc, one VGPR per real number; the op
+stream -- matrices, phase factors, tables -- stays double precision in memory and
+is converted with v_cvt_f32_f64 as it is read).
+
+Register map (island-private, declared as clobbers to the compiler), complex128:
   v[T0+4k .. T0+4k+3]   tile slot k: x = v[+0:+1], y = v[+2:+3]; T0 = 40
   v16..v39              24 temporaries, reused per op kind (see V below)
                         => 168 VGPRs at RB=5: THREE waves per SIMD
@@ -31,20 +36,42 @@ T0 = 40
 TEMP_LO, TEMP_HI = 16, 39
 
 
+class DT:
+  """Element type of the tile: wide=True complex128, wide=False complex64."""
+  wide = True
+
+
+def W():
+  return 2 if DT.wide else 1          # VGPRs per real number
+
+
 def T(k):
-  return T0 + 4 * k
-
-
-def X(k):
-  return f'v[{T(k)}:{T(k) + 1}]'
-
-
-def Y(k):
-  return f'v[{T(k) + 2}:{T(k) + 3}]'
+  return T0 + 2 * W() * k
 
 
 def V2(i):
-  return f'v[{i}:{i + 1}]'
+  """The real number held at temp index i (a VGPR pair for f64, one VGPR for f32)."""
+  return f'v[{i}:{i + 1}]' if DT.wide else f'v{i}'
+
+
+def X(k):
+  return V2(T(k))
+
+
+def Y(k):
+  return V2(T(k) + W())
+
+
+def MUL():
+  return 'v_mul_f64' if DT.wide else 'v_mul_f32'
+
+
+def FMA():
+  return 'v_fma_f64' if DT.wide else 'v_fma_f32'
+
+
+def MOV():
+  return 'v_mov_b64' if DT.wide else 'v_mov_b32'
 
 
 class Asm:
@@ -87,24 +114,25 @@ def cmul_slots(a, slots, fr, fi):
   tm = [V2(t) for t in D_TMP]
   # t = y*fi ; y = y*fr ; y += x*fi ; x = x*fr - t   (4 FP64 ops, result in place)
   for t, k in zip(tm, slots):
-    a(f'v_mul_f64 {t}, {Y(k)}, {fi}')
+    a(MUL() + f' {t}, {Y(k)}, {fi}')
   for t, k in zip(tm, slots):
-    a(f'v_mul_f64 {Y(k)}, {Y(k)}, {fr}')
+    a(MUL() + f' {Y(k)}, {Y(k)}, {fr}')
   for t, k in zip(tm, slots):
-    a(f'v_fma_f64 {Y(k)}, {X(k)}, {fi}, {Y(k)}')
+    a(FMA() + f' {Y(k)}, {X(k)}, {fi}, {Y(k)}')
   for t, k in zip(tm, slots):
-    a(f'v_fma_f64 {X(k)}, {X(k)}, {fr}, -{t}')
+    a(FMA() + f' {X(k)}, {X(k)}, {fr}, -{t}')
 
 
 def cmul_vv(a, xr, xi, fr, fi, tmp):
   """(xr,xi) *= (fr,fi), all 64-bit register pairs (VGPR or SGPR factor)."""
-  a(f'v_mul_f64 {tmp}, {xi}, {fi}')
-  a(f'v_mul_f64 {xi}, {xi}, {fr}')
-  a(f'v_fma_f64 {xi}, {xr}, {fi}, {xi}')
-  a(f'v_fma_f64 {xr}, {xr}, {fr}, -{tmp}')
+  a(MUL() + f' {tmp}, {xi}, {fi}')
+  a(MUL() + f' {xi}, {xi}, {fr}')
+  a(FMA() + f' {xi}, {xr}, {fi}, {xi}')
+  a(FMA() + f' {xr}, {xr}, {fr}, -{tmp}')
 
 
-def gen(rb):
+def gen(rb, wide=True):
+  DT.wide = wide
   nr = 1 << rb
   a = Asm()
   batch = min(8, nr)
@@ -117,10 +145,12 @@ def gen(rb):
         k = batch * j + i
         a(f's_add_u32 s98, %0, s{52 + 2 * i}')
         a(f's_addc_u32 s99, %1, s{53 + 2 * i}')
+        dw = 'dwordx4' if DT.wide else 'dwordx2'
+        regs = f'v[{T(k)}:{T(k) + 2 * W() - 1}]'
         if store:
-          a(f'global_store_dwordx4 %4, v[{T(k)}:{T(k) + 3}], s[98:99]' + NT)
+          a(f'global_store_{dw} %4, {regs}, s[98:99]' + NT)
         else:
-          a(f'global_load_dwordx4 v[{T(k)}:{T(k) + 3}], %4, s[98:99]' + NT)
+          a(f'global_load_{dw} {regs}, %4, s[98:99]' + NT)
 
   # ---- prologue: parameters, then one 1-KiB global_load_dwordx4 per slot ------------
   a('s_load_dwordx4 s[36:39], %2, 0x0')   # ops cursor, groups base
@@ -164,11 +194,21 @@ def gen(rb):
   a(f's_branch {L("L_op")}')
 
   # ---- dense 2x2 on register bit b: in-place butterflies ----------------------------
-  g = {'g0r': 's[52:53]', 'g0i': 's[54:55]', 'g1r': 's[56:57]', 'g1i': 's[58:59]',
-       'g2r': 's[60:61]', 'g2i': 's[62:63]', 'g3r': 's[64:65]', 'g3i': 's[66:67]'}
+  gnames = ['g0r', 'g0i', 'g1r', 'g1i', 'g2r', 'g2i', 'g3r', 'g3i']
+  if DT.wide:
+    g = {nm: f's[{52 + 2 * i}:{53 + 2 * i}]' for i, nm in enumerate(gnames)}
+  else:
+    g = {nm: f'v{16 + i}' for i, nm in enumerate(gnames)}
+
+  def load_matrix_f32(first=16):
+    """complex64 tile: the op's double-precision matrix -> 8 floats in v[first..first+7]."""
+    if not DT.wide:
+      for i in range(8):
+        a(f'v_cvt_f32_f64 v{first + i}, s[{52 + 2 * i}:{53 + 2 * i}]')
   t0, t1, t2, t3 = (V2(t) for t in R_T)
   for b in range(rb):
     a.label(f'L_reg{b}')
+    load_matrix_f32()
     for h in range(nr // 2):
       k0 = ((h >> b) << (b + 1)) | (h & ((1 << b) - 1))
       k1 = k0 | (1 << b)
@@ -177,27 +217,27 @@ def gen(rb):
       a('s_cmp_eq_u32 s74, 0')
       a(f's_cbranch_scc0 {L(skip)}')
       ar, ai, br, bi = X(k0), Y(k0), X(k1), Y(k1)
-      a(f'v_mul_f64 {t0}, {g["g0r"]}, {ar}')
-      a(f'v_mul_f64 {t1}, {g["g0r"]}, {ai}')
-      a(f'v_mul_f64 {t2}, {g["g2r"]}, {ar}')
-      a(f'v_mul_f64 {t3}, {g["g2r"]}, {ai}')
-      a(f'v_fma_f64 {t0}, -{g["g0i"]}, {ai}, {t0}')
-      a(f'v_fma_f64 {t1}, {g["g0i"]}, {ar}, {t1}')
-      a(f'v_fma_f64 {t2}, -{g["g2i"]}, {ai}, {t2}')
-      a(f'v_fma_f64 {t3}, {g["g2i"]}, {ar}, {t3}')
-      a(f'v_fma_f64 {t0}, {g["g1r"]}, {br}, {t0}')
-      a(f'v_fma_f64 {t1}, {g["g1r"]}, {bi}, {t1}')
-      a(f'v_fma_f64 {t2}, {g["g3r"]}, {br}, {t2}')
-      a(f'v_fma_f64 {t3}, {g["g3r"]}, {bi}, {t3}')
-      a(f'v_fma_f64 {t0}, -{g["g1i"]}, {bi}, {t0}')
-      a(f'v_fma_f64 {t1}, {g["g1i"]}, {br}, {t1}')
-      a(f'v_fma_f64 {t2}, -{g["g3i"]}, {bi}, {t2}')
-      a(f'v_fma_f64 {t3}, {g["g3i"]}, {br}, {t3}')
+      a(MUL() + f' {t0}, {g["g0r"]}, {ar}')
+      a(MUL() + f' {t1}, {g["g0r"]}, {ai}')
+      a(MUL() + f' {t2}, {g["g2r"]}, {ar}')
+      a(MUL() + f' {t3}, {g["g2r"]}, {ai}')
+      a(FMA() + f' {t0}, -{g["g0i"]}, {ai}, {t0}')
+      a(FMA() + f' {t1}, {g["g0i"]}, {ar}, {t1}')
+      a(FMA() + f' {t2}, -{g["g2i"]}, {ai}, {t2}')
+      a(FMA() + f' {t3}, {g["g2i"]}, {ar}, {t3}')
+      a(FMA() + f' {t0}, {g["g1r"]}, {br}, {t0}')
+      a(FMA() + f' {t1}, {g["g1r"]}, {bi}, {t1}')
+      a(FMA() + f' {t2}, {g["g3r"]}, {br}, {t2}')
+      a(FMA() + f' {t3}, {g["g3r"]}, {bi}, {t3}')
+      a(FMA() + f' {t0}, -{g["g1i"]}, {bi}, {t0}')
+      a(FMA() + f' {t1}, {g["g1i"]}, {br}, {t1}')
+      a(FMA() + f' {t2}, -{g["g3i"]}, {bi}, {t2}')
+      a(FMA() + f' {t3}, {g["g3i"]}, {br}, {t3}')
       a('s_and_saveexec_b64 s[70:71], s[68:69]')
-      a(f'v_mov_b64 {ar}, {t0}')
-      a(f'v_mov_b64 {ai}, {t1}')
-      a(f'v_mov_b64 {br}, {t2}')
-      a(f'v_mov_b64 {bi}, {t3}')
+      a(MOV() + f' {ar}, {t0}')
+      a(MOV() + f' {ai}, {t1}')
+      a(MOV() + f' {br}, {t2}')
+      a(MOV() + f' {bi}, {t3}')
       a('s_mov_b64 exec, s[70:71]')
       a.label(skip)
     a(f's_branch {L("L_next")}')
@@ -212,6 +252,7 @@ def gen(rb):
   a(f's_branch {L("L_next")}')
   for b in range(rb):
     a.label(f'L_rr{b}')
+    load_matrix_f32()
     pairs = []
     for h in range(nr // 2):
       k0 = ((h >> b) << (b + 1)) | (h & ((1 << b) - 1))
@@ -220,20 +261,20 @@ def gen(rb):
       grp = pairs[i:i + 2]
       tmps = [(V2(R_T[2 * j]), V2(R_T[2 * j + 1])) for j in range(len(grp))]
       for (k0, k1), (ta, tb) in zip(grp, tmps):
-        a(f'v_mul_f64 {ta}, {g["g0r"]}, {X(k0)}')
-        a(f'v_mul_f64 {tb}, {g["g0r"]}, {Y(k0)}')
+        a(MUL() + f' {ta}, {g["g0r"]}, {X(k0)}')
+        a(MUL() + f' {tb}, {g["g0r"]}, {Y(k0)}')
       for (k0, k1), (ta, tb) in zip(grp, tmps):
-        a(f'v_fma_f64 {ta}, {g["g1r"]}, {X(k1)}, {ta}')
-        a(f'v_fma_f64 {tb}, {g["g1r"]}, {Y(k1)}, {tb}')
+        a(FMA() + f' {ta}, {g["g1r"]}, {X(k1)}, {ta}')
+        a(FMA() + f' {tb}, {g["g1r"]}, {Y(k1)}, {tb}')
       for (k0, k1), (ta, tb) in zip(grp, tmps):
-        a(f'v_mul_f64 {X(k1)}, {g["g3r"]}, {X(k1)}')
-        a(f'v_mul_f64 {Y(k1)}, {g["g3r"]}, {Y(k1)}')
+        a(MUL() + f' {X(k1)}, {g["g3r"]}, {X(k1)}')
+        a(MUL() + f' {Y(k1)}, {g["g3r"]}, {Y(k1)}')
       for (k0, k1), (ta, tb) in zip(grp, tmps):
-        a(f'v_fma_f64 {X(k1)}, {g["g2r"]}, {X(k0)}, {X(k1)}')
-        a(f'v_fma_f64 {Y(k1)}, {g["g2r"]}, {Y(k0)}, {Y(k1)}')
+        a(FMA() + f' {X(k1)}, {g["g2r"]}, {X(k0)}, {X(k1)}')
+        a(FMA() + f' {Y(k1)}, {g["g2r"]}, {Y(k0)}, {Y(k1)}')
       for (k0, k1), (ta, tb) in zip(grp, tmps):
-        a(f'v_mov_b64 {X(k0)}, {ta}')
-        a(f'v_mov_b64 {Y(k0)}, {tb}')
+        a(MOV() + f' {X(k0)}, {ta}')
+        a(MOV() + f' {Y(k0)}, {tb}')
     a(f's_branch {L("L_next")}')
   # lane bit, real: new = ca*mine + cb*other with real per-lane ca, cb -- 4 FP64 ops per slot
   a.label('L_lane_real')
@@ -244,29 +285,34 @@ def gen(rb):
   a(f'v_cmp_ne_u32 vcc, 0, v{LN_TMP}')
   a('s_bitcmp1_b32 s51, 1')                     # USE_C needs complex coefficients: generic path
   a(f's_cbranch_scc1 {L("L_lane_c1")}')
-  for v, (lo, hi) in ((LN_COEF['car'], (52, 64)), (LN_COEF['cbr'], (56, 60))):
-    for d in range(2):
-      a(f'v_mov_b32 v{v + d}, s{lo + d}')
-      a(f'v_mov_b32 v{LN_TMP}, s{hi + d}')
-      a(f'v_cndmask_b32 v{v + d}, v{v + d}, v{LN_TMP}, vcc')
+  if DT.wide:
+    for v, (lo, hi) in ((LN_COEF['car'], (52, 64)), (LN_COEF['cbr'], (56, 60))):
+      for d in range(2):
+        a(f'v_mov_b32 v{v + d}, s{lo + d}')
+        a(f'v_mov_b32 v{LN_TMP}, s{hi + d}')
+        a(f'v_cndmask_b32 v{v + d}, v{v + d}, v{LN_TMP}, vcc')
+  else:
+    load_matrix_f32(26)                          # g0r g0i g1r g1i g2r g2i g3r g3i -> v26..v33
+    a(f'v_cndmask_b32 v{LN_COEF["car"]}, v26, v32, vcc')   # hi ? g3r : g0r
+    a(f'v_cndmask_b32 v{LN_COEF["cbr"]}, v28, v30, vcc')   # hi ? g2r : g1r
   rca, rcb = V2(LN_COEF['car']), V2(LN_COEF['cbr'])
 
   def shuf_r(k, buf):
-    for d in range(4):
+    for d in range(2 * W()):
       a(f'ds_bpermute_b32 v{buf + d}, v{LN_ADDR}, v{T(k) + d}')
 
   shuf_r(0, LN_BUF[0])
   for k in range(nr):
     if k + 1 < nr:
       shuf_r(k + 1, LN_BUF[(k + 1) & 1])
-      a('s_waitcnt lgkmcnt(4)')
+      a(f's_waitcnt lgkmcnt({2 * W()})')
     else:
       a('s_waitcnt lgkmcnt(0)')
     buf = LN_BUF[k & 1]
-    a(f'v_mul_f64 {X(k)}, {rca}, {X(k)}')
-    a(f'v_mul_f64 {Y(k)}, {rca}, {Y(k)}')
-    a(f'v_fma_f64 {X(k)}, {rcb}, {V2(buf)}, {X(k)}')
-    a(f'v_fma_f64 {Y(k)}, {rcb}, {V2(buf + 2)}, {Y(k)}')
+    a(MUL() + f' {X(k)}, {rca}, {X(k)}')
+    a(MUL() + f' {Y(k)}, {rca}, {Y(k)}')
+    a(FMA() + f' {X(k)}, {rcb}, {V2(buf)}, {X(k)}')
+    a(FMA() + f' {Y(k)}, {rcb}, {V2(buf + W())}, {Y(k)}')
   a(f's_branch {L("L_next")}')
 
   # ---- dense 2x2 on a lane bit: partner via ds_bpermute -------------------------------
@@ -281,19 +327,29 @@ def gen(rb):
   # registers: move it to v[34:37] and fetch the partner lane's c into v[26:29] first
   a('s_bitcmp1_b32 s51, 1')
   a(f's_cbranch_scc0 {L("L_lane_c0")}')
-  a(f'v_mov_b64 {V2(34)}, {V2(D_C[0])}')
-  a(f'v_mov_b64 {V2(36)}, {V2(D_C[1])}')
-  for d in range(4):
-    a(f'ds_bpermute_b32 v{LN_BUF[0] + d}, v{LN_ADDR}, v{34 + d}')
+  cc = 34 if DT.wide else 38                        # f64: v[34:35], v[36:37]; f32: v38, v39
+  a(MOV() + f' {V2(cc)}, {V2(D_C[0])}')
+  a(MOV() + f' {V2(cc + W())}, {V2(D_C[1])}')
+  for d in range(2 * W()):
+    a(f'ds_bpermute_b32 v{LN_BUF[0] + d}, v{LN_ADDR}, v{cc + d}')
   a.label('L_lane_c0')
   # new = ca*mine + cb*other ; ca = hi ? g3 : g0 ; cb = hi ? g2 : g1
   src = {'car': (52, 64), 'cai': (54, 66), 'cbr': (56, 60), 'cbi': (58, 62)}
-  for name, v in LN_COEF.items():
-    lo, hi = src[name]
-    for d in range(2):
-      a(f'v_mov_b32 v{v + d}, s{lo + d}')
-      a(f'v_mov_b32 v{LN_TMP}, s{hi + d}')
-      a(f'v_cndmask_b32 v{v + d}, v{v + d}, v{LN_TMP}, vcc')
+  if DT.wide:
+    for name, v in LN_COEF.items():
+      lo, hi = src[name]
+      for d in range(2):
+        a(f'v_mov_b32 v{v + d}, s{lo + d}')
+        a(f'v_mov_b32 v{LN_TMP}, s{hi + d}')
+        a(f'v_cndmask_b32 v{v + d}, v{v + d}, v{LN_TMP}, vcc')
+  else:
+    # the partner's c (USE_C) may be arriving in v26,v27: convert the matrix into the
+    # cmul temporaries' neighbourhood instead (v30..v37), then select per lane
+    load_matrix_f32(30)
+    a(f'v_cndmask_b32 v{LN_COEF["car"]}, v30, v36, vcc')   # hi ? g3r : g0r
+    a(f'v_cndmask_b32 v{LN_COEF["cai"]}, v31, v37, vcc')   # hi ? g3i : g0i
+    a(f'v_cndmask_b32 v{LN_COEF["cbr"]}, v32, v34, vcc')   # hi ? g2r : g1r
+    a(f'v_cndmask_b32 v{LN_COEF["cbi"]}, v33, v35, vcc')   # hi ? g2i : g1i
   car, cai, cbr, cbi = (V2(LN_COEF[n]) for n in ('car', 'cai', 'cbr', 'cbi'))
   # USE_C (flags bit 1): the preceding DIAG op left its per-lane factor c un-applied;
   # H.diag(c) acts as  new = (ca c_mine) mine + (cb c_other) other  -- two complex
@@ -301,28 +357,28 @@ def gen(rb):
   a('s_bitcmp1_b32 s51, 1')
   a(f's_cbranch_scc0 {L("L_lane_nc")}')
   a('s_waitcnt lgkmcnt(0)')
-  cmul_vv(a, car, cai, V2(34), V2(36), V2(LN_BUF[1]))
-  cmul_vv(a, cbr, cbi, V2(LN_BUF[0]), V2(LN_BUF[0] + 2), V2(LN_BUF[1]))
+  cmul_vv(a, car, cai, V2(cc), V2(cc + W()), V2(LN_BUF[1]))
+  cmul_vv(a, cbr, cbi, V2(LN_BUF[0]), V2(LN_BUF[0] + W()), V2(LN_BUF[1]))
   a.label('L_lane_nc')
 
   def shuf(k, buf):
-    for d in range(4):
+    for d in range(2 * W()):
       a(f'ds_bpermute_b32 v{buf + d}, v{LN_ADDR}, v{T(k) + d}')
 
   def combine(k, buf):
-    orr, oi = V2(buf), V2(buf + 2)
+    orr, oi = V2(buf), V2(buf + W())
     u0, u1 = V2(LN_T[0]), V2(LN_T[1])
-    a(f'v_mul_f64 {u0}, {car}, {X(k)}')
-    a(f'v_mul_f64 {u1}, {car}, {Y(k)}')
-    a(f'v_fma_f64 {u0}, -{cai}, {Y(k)}, {u0}')
-    a(f'v_fma_f64 {u1}, {cai}, {X(k)}, {u1}')
-    a(f'v_fma_f64 {u0}, {cbr}, {orr}, {u0}')
-    a(f'v_fma_f64 {u1}, {cbr}, {oi}, {u1}')
-    a(f'v_fma_f64 {u0}, -{cbi}, {oi}, {u0}')
-    a(f'v_fma_f64 {u1}, {cbi}, {orr}, {u1}')
+    a(MUL() + f' {u0}, {car}, {X(k)}')
+    a(MUL() + f' {u1}, {car}, {Y(k)}')
+    a(FMA() + f' {u0}, -{cai}, {Y(k)}, {u0}')
+    a(FMA() + f' {u1}, {cai}, {X(k)}, {u1}')
+    a(FMA() + f' {u0}, {cbr}, {orr}, {u0}')
+    a(FMA() + f' {u1}, {cbr}, {oi}, {u1}')
+    a(FMA() + f' {u0}, -{cbi}, {oi}, {u0}')
+    a(FMA() + f' {u1}, {cbi}, {orr}, {u1}')
     a('s_and_saveexec_b64 s[70:71], s[68:69]')
-    a(f'v_mov_b64 {X(k)}, {u0}')
-    a(f'v_mov_b64 {Y(k)}, {u1}')
+    a(MOV() + f' {X(k)}, {u0}')
+    a(MOV() + f' {Y(k)}, {u1}')
     a('s_mov_b64 exec, s[70:71]')
 
   a('s_cmp_eq_u32 s46, 0')
@@ -332,7 +388,7 @@ def gen(rb):
   for k in range(nr):
     if k + 1 < nr:
       shuf(k + 1, LN_BUF[(k + 1) & 1])
-      a('s_waitcnt lgkmcnt(4)')
+      a(f's_waitcnt lgkmcnt({2 * W()})')
     else:
       a('s_waitcnt lgkmcnt(0)')
     combine(k, LN_BUF[k & 1])
@@ -359,11 +415,25 @@ def gen(rb):
   ur, ui = V2(D_U[0]), V2(D_U[1])
   fr, fi = V2(D_F[0]), V2(D_F[1])
   dt = V2(D_TMP[0])
+
+  def cmul_su(sre, sim):
+    """u *= the double-precision factor held in two SGPR pairs."""
+    if DT.wide:
+      cmul_vv(a, ur, ui, sre, sim, dt)
+    else:
+      a(f'v_cvt_f32_f64 v38, {sre}')          # v34..v37 may be receiving a lane-table entry
+      a(f'v_cvt_f32_f64 v39, {sim}')
+      cmul_vv(a, ur, ui, 'v38', 'v39', dt)
+
   a.label('L_diag')
-  a(f'v_mov_b32 v{D_C[0]}, 0')
-  a(f'v_mov_b32 v{D_C[0] + 1}, 0x3ff00000')   # c = 1.0 + 0.0i
-  a(f'v_mov_b32 v{D_C[1]}, 0')
-  a(f'v_mov_b32 v{D_C[1] + 1}, 0')
+  if DT.wide:
+    a(f'v_mov_b32 v{D_C[0]}, 0')
+    a(f'v_mov_b32 v{D_C[0] + 1}, 0x3ff00000')   # c = 1.0 + 0.0i
+    a(f'v_mov_b32 v{D_C[1]}, 0')
+    a(f'v_mov_b32 v{D_C[1] + 1}, 0')
+  else:
+    a(f'v_mov_b32 v{D_C[0]}, 1.0')
+    a(f'v_mov_b32 v{D_C[1]}, 0')
   a('s_mov_b32 s75, 0')                        # c modified?
   a('s_cmp_eq_u32 s47, 0')
   a(f's_cbranch_scc1 {L("L_next")}')
@@ -376,16 +446,24 @@ def gen(rb):
   a('s_load_dwordx16 s[52:67], s[92:93], 0x0')
   a.label('L_grp')
   a('s_waitcnt lgkmcnt(0)')
-  a(f'v_mov_b32 v{D_U[0]}, s56')
-  a(f'v_mov_b32 v{D_U[0] + 1}, s57')           # u = phi0 (wave-uniform value held in VGPRs)
-  a(f'v_mov_b32 v{D_U[1]}, s58')
-  a(f'v_mov_b32 v{D_U[1] + 1}, s59')
+  if DT.wide:
+    a(f'v_mov_b32 v{D_U[0]}, s56')
+    a(f'v_mov_b32 v{D_U[0] + 1}, s57')         # u = phi0 (wave-uniform value held in VGPRs)
+    a(f'v_mov_b32 v{D_U[1]}, s58')
+    a(f'v_mov_b32 v{D_U[1] + 1}, s59')
+  else:
+    a(f'v_cvt_f32_f64 v{D_U[0]}, s[56:57]')
+    a(f'v_cvt_f32_f64 v{D_U[1]}, s[58:59]')
   a('s_bitcmp1_b32 s60, 0')                    # LTAB: start the 1-KiB lane-table load early
   a(f's_cbranch_scc0 {L("L_g1")}')
   a('s_lshl_b32 s74, s61, 4')
   a('s_add_u32 s98, s48, s74')
   a('s_addc_u32 s99, s49, 0')
-  a(f'global_load_dwordx4 v[{D_LTAB}:{D_LTAB + 3}], %4, s[98:99]')
+  if DT.wide:
+    a(f'global_load_dwordx4 v[{D_LTAB}:{D_LTAB + 3}], %4, s[98:99]')
+  else:                                          # table entries are 16 B, %4 is lane*8
+    a(f'v_lshlrev_b32 v{V_A}, 1, %4')
+    a(f'global_load_dwordx4 v[{D_LTAB}:{D_LTAB + 3}], v{V_A}, s[98:99]')
   a.label('L_g1')
   a('s_cmp_eq_u32 s62, 0')
   a(f's_cbranch_scc1 {L("L_g2")}')
@@ -405,7 +483,7 @@ def gen(rb):
     if t:
       a(f's_cmp_le_u32 s62, {t}')
       a(f's_cbranch_scc1 {L("L_g2")}')
-    cmul_vv(a, ur, ui, f's[{76 + 4 * t}:{77 + 4 * t}]', f's[{78 + 4 * t}:{79 + 4 * t}]', dt)
+    cmul_su(f's[{76 + 4 * t}:{77 + 4 * t}]', f's[{78 + 4 * t}:{79 + 4 * t}]')
   a.label('L_g2')
   a('s_cmp_eq_u32 s55, 0')
   a(f's_cbranch_scc1 {L("L_grp_f")}')
@@ -420,7 +498,7 @@ def gen(rb):
   a('s_and_b64 s[72:73], %3, s[84:85]')
   a('s_cmp_eq_u64 s[72:73], s[84:85]')
   a(f's_cbranch_scc0 {L("L_ot_n")}')
-  cmul_vv(a, ur, ui, 's[88:89]', 's[90:91]', dt)
+  cmul_su('s[88:89]', 's[90:91]')
   a.label('L_ot_n')
   a('s_add_u32 s94, s94, 24')
   a('s_addc_u32 s95, s95, 0')
@@ -431,20 +509,29 @@ def gen(rb):
   a('s_bitcmp1_b32 s60, 0')
   a(f's_cbranch_scc0 {L("L_g3")}')
   a('s_waitcnt vmcnt(0)')                      # f = ltab[lane] * u
-  lt_r, lt_i = V2(D_LTAB), V2(D_LTAB + 2)
-  a(f'v_mul_f64 {fr}, {lt_r}, {ur}')
-  a(f'v_mul_f64 {fi}, {lt_r}, {ui}')
-  a(f'v_fma_f64 {fr}, -{lt_i}, {ui}, {fr}')
-  a(f'v_fma_f64 {fi}, {lt_i}, {ur}, {fi}')
+  if DT.wide:
+    lt_r, lt_i = V2(D_LTAB), V2(D_LTAB + 2)
+  else:
+    a(f'v_cvt_f32_f64 v38, v[{D_LTAB}:{D_LTAB + 1}]')
+    a(f'v_cvt_f32_f64 v39, v[{D_LTAB + 2}:{D_LTAB + 3}]')
+    lt_r, lt_i = 'v38', 'v39'
+  a(MUL() + f' {fr}, {lt_r}, {ur}')
+  a(MUL() + f' {fi}, {lt_r}, {ui}')
+  a(FMA() + f' {fr}, -{lt_i}, {ui}, {fr}')
+  a(FMA() + f' {fi}, {lt_i}, {ur}, {fi}')
   a(f's_branch {L("L_g4")}')
   a.label('L_g3')                              # f = lane_ok ? u : 1
   a(f'v_and_b32 v{V_A}, s52, %5')
   a(f'v_cmp_eq_u32 vcc, s52, v{V_A}')
-  a(f'v_mov_b32 v{V_B}, 0x3ff00000')
-  a(f'v_cndmask_b32 v{D_F[0]}, 0, v{D_U[0]}, vcc')
-  a(f'v_cndmask_b32 v{D_F[0] + 1}, v{V_B}, v{D_U[0] + 1}, vcc')
-  a(f'v_cndmask_b32 v{D_F[1]}, 0, v{D_U[1]}, vcc')
-  a(f'v_cndmask_b32 v{D_F[1] + 1}, 0, v{D_U[1] + 1}, vcc')
+  if DT.wide:
+    a(f'v_mov_b32 v{V_B}, 0x3ff00000')
+    a(f'v_cndmask_b32 v{D_F[0]}, 0, v{D_U[0]}, vcc')
+    a(f'v_cndmask_b32 v{D_F[0] + 1}, v{V_B}, v{D_U[0] + 1}, vcc')
+    a(f'v_cndmask_b32 v{D_F[1]}, 0, v{D_U[1]}, vcc')
+    a(f'v_cndmask_b32 v{D_F[1] + 1}, 0, v{D_U[1] + 1}, vcc')
+  else:
+    a(f'v_cndmask_b32 v{D_F[0]}, 1.0, v{D_U[0]}, vcc')
+    a(f'v_cndmask_b32 v{D_F[1]}, 0, v{D_U[1]}, vcc')
   a.label('L_g4')
   # the header is consumed: remember reg_mask, advance, and prefetch the NEXT group's
   # header into the same SGPRs while the VALU applies this group's factor
@@ -496,11 +583,11 @@ def gen(rb):
   tile_io(store=True)
   a('s_nop 0')
 
-  clob = ([f'v{i}' for i in range(TEMP_LO, T0 + 4 * nr)] + [f's{i}' for i in range(36, 100)] +
+  clob = ([f'v{i}' for i in range(TEMP_LO, T0 + 2 * W() * nr)] + [f's{i}' for i in range(36, 100)] +
           ['vcc', 'scc', 'memory'])
   body = '\n'.join(f'    "{ln}\\n\\t"' for ln in a.lines)
   cl = ', '.join(f'"{c}"' for c in clob)
-  return (f'// GENERATED by tools/gen_sweep_asm.py (RB={rb}) -- do not edit.\n'
+  return (f'// GENERATED by tools/gen_sweep_asm.py (RB={rb}, {"complex128" if DT.wide else "complex64"}) -- do not edit.\n'
           f'asm volatile(\n{body}\n'
           '    :\n'
           '    : "s"(base_lo), "s"(base_hi), "s"(prm), "s"(tile_idx), "v"(voff), "v"(lane_u), "v"(it_lo), "v"(it_hi)\n'
@@ -509,11 +596,12 @@ def gen(rb):
 
 def main():
   out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'qcc_amd', 'csrc')
-  for rb in (2, 3, 4, 5):
-    path = os.path.join(out, f'sweep_island_rb{rb}.inc')
-    with open(path, 'w') as f:
-      f.write(gen(rb))
-    print('wrote', path, sum(1 for _ in open(path)), 'lines')
+  for wide in (True, False):
+    for rb in (2, 3, 4, 5):
+      path = os.path.join(out, f'sweep_island_rb{rb}.inc' if wide else f'sweep_island_f32_rb{rb}.inc')
+      with open(path, 'w') as f:
+        f.write(gen(rb, wide))
+      print('wrote', path, sum(1 for _ in open(path)), 'lines')
 
 
 if __name__ == '__main__':
