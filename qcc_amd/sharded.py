@@ -57,7 +57,7 @@ class ShardedState:
   """complex128 state sharded by its top log2(P) physical index bits."""
 
   def __init__(self, nbits, fusion=1, local_rank=None, *, engine_factory=None, backend=None,
-               chunk_amps=1 << 24, exchange='alltoall'):
+               chunk_amps=1 << 22, exchange='alltoall'):
     import torch
     import torch.distributed as dist
     self.torch, self.dist = torch, dist
@@ -216,15 +216,17 @@ class ShardedState:
     self.gates += len(cq)
 
   # ------------------------------------------------------------------ the exchange step
-  def _swap_chunks(self, pairs):
-    """pairs: [(peer, view)] -- send `view` to peer and replace it by what peer sends.
+  def _post_swap(self, pairs, parity):
+    """Start `send view to peer / receive peer's data` for every (peer, view).
 
-    NCCL/RCCL moves HBM views directly; with the gloo backend and a GPU-resident
-    shard (used to test this layer with two processes on ONE GPU) the chunks are
-    staged through host memory."""
+    Returns (requests, [(view, landing buffer)]).  NCCL/RCCL moves HBM views
+    directly into one of two staging halves; with the gloo backend and a
+    GPU-resident shard (used to test this layer with several processes on ONE GPU)
+    the chunks are staged through host memory."""
     torch, dist = self.torch, self.dist
     via_host = self.buf.is_cuda and dist.get_backend() == 'gloo'
     ops, recv = [], []
+    half = self._staging.numel() // 2
     for slot, (peer, view) in enumerate(pairs):
       n = view.numel()
       if via_host:
@@ -232,14 +234,33 @@ class ShardedState:
         dst = torch.empty_like(src)
       else:
         src = view
-        dst = self._staging[self._stage_stride * slot: self._stage_stride * slot + n]
+        lo = parity * half + self._stage_stride * slot
+        dst = self._staging[lo: lo + n]
       ops.append(dist.P2POp(dist.isend, src, peer))
       ops.append(dist.P2POp(dist.irecv, dst, peer))
       recv.append((view, dst))
-    for req in dist.batch_isend_irecv(ops):
+    return dist.batch_isend_irecv(ops), recv
+
+  @staticmethod
+  def _finish_swap(posted):
+    reqs, recv = posted
+    for req in reqs:
       req.wait()
     for view, dst in recv:
       view.copy_(dst)
+
+  def _swap_all(self, chunk_lists):
+    """Run the chunk exchanges double-buffered: while chunk i is on the links, the
+    landing buffer of chunk i-1 is copied into place (the copy is ~15% of a chunk's
+    link time at xGMI rates, so this hides it)."""
+    prev = None
+    for i, pairs in enumerate(chunk_lists):
+      cur = self._post_swap(pairs, i & 1)
+      if prev is not None:
+        self._finish_swap(prev)
+      prev = cur
+    if prev is not None:
+      self._finish_swap(prev)
 
   def _exchange(self, shard_phys_bit, base=None):
     if self.exchange_mode == 'alltoall':
@@ -301,16 +322,19 @@ class ShardedState:
     stride = run << g
     chunk = min(self.chunk, run)
     self.eng.sync()
-    need = 2 * chunk * (P - 1)
+    need = 2 * (2 * chunk * (P - 1))                 # two halves: double buffering
     if self._staging is None or self._staging.numel() < need:
       self._staging = torch.empty(need, dtype=self.buf.dtype, device=self.buf.device)
     self._stage_stride = 2 * chunk
     peers = [j for j in range(P) if j != r]
-    for hi in range(nruns):
-      for off in range(0, run, chunk):
-        n = min(chunk, run - off)
-        self._swap_chunks([(j, self.buf[2 * (hi * stride + j * run + off): 2 * (hi * stride + j * run + off + n)])
-                           for j in peers])
+
+    def chunks():
+      for hi in range(nruns):
+        for off in range(0, run, chunk):
+          n = min(chunk, run - off)
+          yield [(j, self.buf[2 * (hi * stride + j * run + off): 2 * (hi * stride + j * run + off + n)])
+                 for j in peers]
+    self._swap_all(chunks())
     if self.buf.is_cuda:
       torch.cuda.synchronize()
     for k in range(g):                               # shard bit k <-> local bit base+k
@@ -330,12 +354,11 @@ class ShardedState:
     half = 1 << top                                   # amplitudes
     start = (1 - mybit) * half                        # the half whose top bit != my shard bit
     self.eng.sync()                                   # kernels done before RCCL touches the shard
-    if self._staging is None or self._staging.numel() < 2 * self.chunk:
-      self._staging = torch.empty(2 * self.chunk, dtype=self.buf.dtype, device=self.buf.device)
+    if self._staging is None or self._staging.numel() < 4 * self.chunk:
+      self._staging = torch.empty(4 * self.chunk, dtype=self.buf.dtype, device=self.buf.device)
     self._stage_stride = 2 * self.chunk
-    for off in range(0, half, self.chunk):
-      n = min(self.chunk, half - off)
-      self._swap_chunks([(partner, self.buf[2 * (start + off): 2 * (start + off + n)])])
+    self._swap_all([(partner, self.buf[2 * (start + off): 2 * (start + min(off + self.chunk, half))])]
+                   for off in range(0, half, self.chunk))
     if self.buf.is_cuda:
       torch.cuda.synchronize()
     # bookkeeping: the two logical bits trade physical homes
