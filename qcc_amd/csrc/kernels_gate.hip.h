@@ -28,7 +28,7 @@
 
 namespace qh {
 
-constexpr int kMaxIns = 8;
+constexpr int kMaxIns = 12;
 
 // Sorted (ascending) list of bit positions at which a bit is inserted into a
 // dense work-item counter to form an amplitude index; `ones` has the inserted

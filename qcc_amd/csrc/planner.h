@@ -45,9 +45,12 @@ inline bool plan_diag(const double g[8], int tgt) {
 }
 
 constexpr int kLaneBits = 6;   // wavefront = 64 lanes
+constexpr int kLaneLow = 3;    // lane bits 0..2 are ALWAYS index bits 0..2 (one 128-byte line per 8 lanes)
+constexpr int kLaneHi = 3;     // lane bits 3..5 sit on index bits 3,4,5 -- or on any three bits <= kMaxLaneHiBit
+constexpr int kMaxLaneHiBit = 27;  // per-lane byte offset must fit the 32-bit voffset of global_load
 constexpr int kMaxRegBits = 5; // 32 amplitudes (128 VGPRs of data) per lane
 constexpr int kMaxSweepOps = 1024;
-constexpr int kMaxInsertBits = 8;  // == kMaxIns of kernels_gate.hip.h (tile enumeration)
+constexpr int kMaxInsertBits = 12;  // == kMaxIns of kernels_gate.hip.h (tile enumeration)
 
 enum : uint32_t { OP_DENSE_REG = 0, OP_DENSE_LANE = 1, OP_DIAG = 2 };
 // A DIAG op directly followed by an uncontrolled dense op on a LANE bit does not
@@ -91,7 +94,8 @@ struct SweepOp {
 
 struct SweepPlan {
   int rb = 0;                      // register bits used by the kernel instance
-  int regpos[kMaxRegBits] = {0};   // ascending physical positions (>= 6)
+  int regpos[kMaxRegBits] = {0};   // ascending physical positions
+  int lanehi[kLaneHi] = {3, 4, 5}; // ascending positions of lane bits 3,4,5 ({3,4,5} = contiguous 1-KiB runs)
   uint64_t fixed_ones = 0;         // local bits fixed to 1 in the tile enumeration
   uint64_t ntiles = 0;             // wavefront tiles to process
   std::vector<SweepOp> ops;
@@ -123,8 +127,8 @@ inline uint64_t gate_alg_bytes(const GateRec &r, int nloc, uint64_t amp_bytes) {
 
 class Planner {
  public:
-  Planner(int nloc, uint64_t shard, int bw, int max_rb)
-      : nloc_(nloc), shard_(shard), amp_bytes_(bw == 128 ? 16 : 8) {
+  Planner(int nloc, uint64_t shard, int bw, int max_rb, bool split_lanes = true)
+      : nloc_(nloc), shard_(shard), amp_bytes_(bw == 128 ? 16 : 8), split_lanes_(split_lanes) {
     rb_cap_ = std::min({max_rb, kMaxRegBits, nloc - kLaneBits});
   }
 
@@ -185,6 +189,7 @@ class Planner {
   uint64_t shard_;
   uint64_t amp_bytes_;
   int rb_cap_;
+  bool split_lanes_;   // allow lane bits 3..5 to sit on arbitrary index bits (8 free tile bits)
   std::vector<uint64_t> alg_override_;
   std::vector<uint32_t> weight_;  // reference gate applications each pending record stands for
 
@@ -271,11 +276,11 @@ class Planner {
     weight->swap(ow);
   }
 
-  // One order-preserving pass over `pending` with a FIXED register-bit set: a gate
-  // is taken if (a) it commutes with every earlier gate that was skipped and (b) its
-  // target is a lane bit or one of `regmask` (diagonal gates always fit).  Returns
-  // the number of gates taken; optionally the indices taken.
-  size_t pass(const std::vector<GateRec> &pending, uint64_t regmask, size_t window,
+  // One order-preserving pass over `pending` with a FIXED tile: a gate is taken if
+  // (a) it commutes with every earlier gate that was skipped and (b) its target is
+  // one of the tile bits `tilemask` (diagonal gates always fit).  Returns the
+  // number of gates taken; optionally the indices taken.
+  size_t pass(const std::vector<GateRec> &pending, uint64_t tilemask, size_t window,
               std::vector<uint8_t> *taken_flags) const {
     uint64_t blocked_all = 0;    // bits a skipped gate acts densely on
     uint64_t blocked_diag = 0;   // bits a skipped gate acts diagonally on
@@ -289,7 +294,7 @@ class Planner {
       const uint64_t diag_bits = r.ctl_mask | (diag ? tb : 0);
       const bool can_pass = !(dense_bits & (blocked_all | blocked_diag)) && !(diag_bits & blocked_all);
       const bool fits = (count < (size_t)kMaxSweepOps) &&
-                        (diag || r.tgt < kLaneBits || ((regmask >> r.tgt) & 1ull));
+                        (diag || ((tilemask >> r.tgt) & 1ull));
       if (can_pass && fits) {
         ++count;
         if (taken_flags) (*taken_flags)[i] = 1;
@@ -303,41 +308,77 @@ class Planner {
     return count;
   }
 
-  // Choose the register bits of a sweep greedily by SIMULATION: add, one at a
-  // time, the candidate bit that lets the most queued gates run in this sweep
-  // (first-come order breaks ties).  For a QFT this reproduces "next five target
-  // bits"; for layered circuits (supremacy, Grover ladders) it picks qubits whose
-  // gates unblock each other instead of the first five that happen to come up.
+  // Tile = index bits {0,1,2} (always) + 3 "lane-high" bits + up to 5 register bits.
+  // With lane-high = {3,4,5} every wave load is one contiguous 1-KiB run; with other
+  // lane-high bits it is eight 128-byte lines (measured 5-10% slower,
+  // tools/membench/splitlane.hip) but the sweep can then take EIGHT new target bits
+  // instead of five.  Split a chosen bit set into (lane-high, register) bits; false
+  // if it does not fit.
+  bool assign_bits(const std::vector<int> &sel, std::vector<int> *lanehi, std::vector<int> *regs) const {
+    std::vector<int> low, other;
+    for (int b : sel) ((b >= kLaneLow && b < kLaneBits) ? low : other).push_back(b);
+    std::sort(low.begin(), low.end());
+    std::sort(other.begin(), other.end());
+    const int need_move = std::max<int>(0, (int)other.size() - rb_cap_);
+    if (need_move > 0 && !split_lanes_) return false;
+    if ((int)low.size() + need_move > kLaneHi) return false;
+    for (int k = 0; k < need_move; ++k)
+      if (other[k] > kMaxLaneHiBit) return false;
+    *lanehi = low;
+    lanehi->insert(lanehi->end(), other.begin(), other.begin() + need_move);
+    regs->assign(other.begin() + need_move, other.end());
+    for (int b = kLaneLow; b < kLaneBits && (int)lanehi->size() < kLaneHi; ++b)   // spare slots: 3,4,5
+      if (std::find(lanehi->begin(), lanehi->end(), b) == lanehi->end()) lanehi->push_back(b);
+    std::sort(lanehi->begin(), lanehi->end());
+    return (int)lanehi->size() == kLaneHi;
+  }
+
+  static uint64_t mask_of(const std::vector<int> &bits) {
+    uint64_t m = 0;
+    for (int b : bits) m |= 1ull << b;
+    return m;
+  }
+
+  // Choose the tile bits of a sweep greedily by SIMULATION: add, one at a time, the
+  // candidate bit that lets the most queued gates run in this sweep (first-come
+  // order breaks ties).  For a QFT this reproduces "the next target bits in order";
+  // for layered circuits (supremacy, Grover ladders) it picks qubits whose gates
+  // unblock each other instead of the first ones that happen to come up.
   SweepPlan build_sweep(const std::vector<GateRec> &pending, const std::vector<uint64_t> &alg,
                         std::vector<GateRec> *rest, std::vector<uint64_t> *rest_alg,
                         std::vector<uint32_t> *rest_w) {
     SweepPlan sp;
     const size_t window = std::min<size_t>(pending.size(), 4096);
-    std::vector<int> cand;       // dense target bits above the lanes, in order of first use
+    const uint64_t always = (1ull << kLaneLow) - 1;
+    std::vector<int> cand;       // dense target bits above bit 2, in order of first use
     for (size_t i = 0; i < window; ++i) {
       const GateRec &r = pending[i];
-      if (!plan_diag(r.g, r.tgt) && r.tgt >= kLaneBits &&
+      if (!plan_diag(r.g, r.tgt) && r.tgt >= kLaneLow &&
           std::find(cand.begin(), cand.end(), r.tgt) == cand.end())
         cand.push_back(r.tgt);
     }
-    uint64_t regmask = 0;
-    std::vector<int> regs;
-    size_t best_total = pass(pending, 0, window, nullptr);
-    while ((int)regs.size() < rb_cap_) {
+    std::vector<int> sel, lanehi, regs;
+    size_t best_total = pass(pending, always, window, nullptr);
+    while ((int)sel.size() < kLaneHi + rb_cap_) {
       int best_bit = -1;
       size_t best = best_total;
       for (int c : cand) {
-        if ((regmask >> c) & 1ull) continue;
-        const size_t sc = pass(pending, regmask | (1ull << c), window, nullptr);
+        if (std::find(sel.begin(), sel.end(), c) != sel.end()) continue;
+        std::vector<int> trial = sel, l, r;
+        trial.push_back(c);
+        if (!assign_bits(trial, &l, &r)) continue;
+        const size_t sc = pass(pending, always | mask_of(trial), window, nullptr);
         if (sc > best) { best = sc; best_bit = c; }
       }
       if (best_bit < 0) break;
-      regs.push_back(best_bit);
-      regmask |= 1ull << best_bit;
+      sel.push_back(best_bit);
       best_total = best;
     }
+    assign_bits(sel, &lanehi, &regs);
+    uint64_t regmask = mask_of(regs);
+    const uint64_t lanemask = always | mask_of(lanehi);
     std::vector<uint8_t> flags(pending.size(), 0);
-    pass(pending, regmask, pending.size(), &flags);
+    pass(pending, lanemask | regmask, pending.size(), &flags);
     std::vector<const GateRec *> taken;
     bool any_dense = false;
     for (size_t i = 0; i < pending.size(); ++i) {
@@ -357,7 +398,7 @@ class Planner {
       rest->erase(rest->begin());
       rest_alg->erase(rest_alg->begin());
       rest_w->erase(rest_w->begin());
-      if (!plan_diag(pending[0].g, pending[0].tgt) && pending[0].tgt >= kLaneBits) {
+      if (!plan_diag(pending[0].g, pending[0].tgt) && !((lanemask >> pending[0].tgt) & 1ull)) {
         regs.assign(1, pending[0].tgt);
         regmask = 1ull << pending[0].tgt;
       }
@@ -368,7 +409,7 @@ class Planner {
     {
       uint64_t used = 0;
       for (const GateRec *r : taken)
-        if (!plan_diag(r->g, r->tgt) && r->tgt >= kLaneBits) used |= 1ull << r->tgt;
+        if (!plan_diag(r->g, r->tgt) && r->tgt >= 0) used |= 1ull << r->tgt;
       std::vector<int> keep;
       for (int p : regs) if ((used >> p) & 1ull) keep.push_back(p);
       regs.swap(keep);
@@ -384,19 +425,20 @@ class Planner {
     }
     regmask = 0;
     for (int p : regs) regmask |= 1ull << p;
-    common &= ~((1ull << kLaneBits) - 1) & ~regmask & ((1ull << nloc_) - 1);
+    common &= ~lanemask & ~regmask & ((1ull << nloc_) - 1);
     // keep enough free bits for the tile: need rb register bits among non-fixed bits
     int rb = std::max<int>((int)regs.size(), std::min(rb_cap_, any_dense ? rb_cap_ : 3));
     while (popc(common) > 0 && nloc_ - kLaneBits - popc(common) < rb) common &= common - 1;
-    while (popc(common) + rb > kMaxInsertBits) common &= common - 1;  // the rest stay per-op controls
+    while (popc(common) + rb + kLaneHi > kMaxInsertBits) common &= common - 1;  // the rest stay per-op controls
     rb = std::min(rb, nloc_ - kLaneBits - popc(common));
     sp.fixed_ones = common;
     // pad the register tile with the lowest free bits (cheap, keeps runs long)
-    for (int p = kLaneBits; p < nloc_ && (int)regs.size() < rb; ++p)
-      if (!((regmask | common) >> p & 1ull)) { regs.push_back(p); regmask |= 1ull << p; }
+    for (int p = kLaneLow; p < nloc_ && (int)regs.size() < rb; ++p)
+      if (!((regmask | common | lanemask) >> p & 1ull)) { regs.push_back(p); regmask |= 1ull << p; }
     std::sort(regs.begin(), regs.end());
     sp.rb = (int)regs.size();
     for (int k = 0; k < sp.rb; ++k) sp.regpos[k] = regs[k];
+    for (int k = 0; k < kLaneHi; ++k) sp.lanehi[k] = lanehi[k];
     sp.ntiles = 1ull << (nloc_ - kLaneBits - sp.rb - popc(common));
     sp.swept_bytes = (sp.ntiles << (kLaneBits + sp.rb)) * amp_bytes_ * 2;
     emit_ops(taken, &sp);
@@ -408,15 +450,27 @@ class Planner {
     return -1;
   }
 
-  // Split an index-bit mask into (lane part, register part, outside part); bits
-  // fixed to one by the enumeration are dropped (always satisfied).
-  void split_mask(const SweepPlan &sp, uint64_t m, uint32_t *lane, uint32_t *reg, uint64_t *outside) const {
+  // lane-bit index (0..5) of a physical index bit, -1 if it is not a lane bit of this tile
+  static int lane_index(const SweepPlan &sp, int pos) {
+    if (pos >= 0 && pos < kLaneLow) return pos;
+    for (int k = 0; k < kLaneHi; ++k) if (sp.lanehi[k] == pos) return kLaneLow + k;
+    return -1;
+  }
+
+  // Split an index-bit mask into (lane part as LANE-INDEX bits, the same lane part
+  // as physical bits, register part, outside part); bits fixed to one by the
+  // enumeration are dropped (always satisfied).
+  void split_mask(const SweepPlan &sp, uint64_t m, uint32_t *lane, uint64_t *lane_phys, uint32_t *reg,
+                  uint64_t *outside) const {
     m &= ~sp.fixed_ones;
-    *lane = (uint32_t)(m & ((1ull << kLaneBits) - 1));
+    *lane = 0;
+    *lane_phys = 0;
     *reg = 0;
     *outside = 0;
-    for (uint64_t t = m >> kLaneBits << kLaneBits; t; t &= t - 1) {
+    for (uint64_t t = m; t; t &= t - 1) {
       const int b = __builtin_ctzll(t);
+      const int li = lane_index(sp, b);
+      if (li >= 0) { *lane |= 1u << li; *lane_phys |= 1ull << b; continue; }
       const int ri = reg_index(sp, b);
       if (ri >= 0) *reg |= 1u << ri; else *outside |= 1ull << b;
     }
@@ -446,12 +500,13 @@ class Planner {
         // non-zero only when THIS flush emitted a DIAG op right in front of the dense op
         const size_t n_ops_after_flush = sp->ops.size() > n_ops_before ? sp->ops.size() : 0;
         SweepOp op{};
-        uint32_t lane, reg; uint64_t outside;
-        split_mask(*sp, r->ctl_mask, &lane, &reg, &outside);
-        op.cm_thread = outside | lane;
+        uint32_t lane, reg; uint64_t outside, lane_phys;
+        split_mask(*sp, r->ctl_mask, &lane, &lane_phys, &reg, &outside);
+        op.cm_thread = outside | lane_phys;   // tested against the thread's physical index
         op.cm_reg = reg;
         memcpy(op.g, r->g, sizeof op.g);
-        if (r->tgt < kLaneBits) { op.kind = OP_DENSE_LANE; op.tb = r->tgt; }
+        const int li = lane_index(*sp, r->tgt);
+        if (li >= 0) { op.kind = OP_DENSE_LANE; op.tb = (uint32_t)li; }
         else { op.kind = OP_DENSE_REG; op.tb = reg_index(*sp, r->tgt); }
         if (r->g[1] == 0.0 && r->g[3] == 0.0 && r->g[5] == 0.0 && r->g[7] == 0.0) op.flags |= OPF_REAL;
         // (for a REAL gate folding would turn its 4-op real path into the 9-op complex
@@ -499,8 +554,8 @@ class Planner {
     };
     std::vector<PGroup> groups;
     for (auto &t : sel) {
-      uint32_t lane, reg; uint64_t outside;
-      split_mask(*sp, t.mask, &lane, &reg, &outside);
+      uint32_t lane, reg; uint64_t outside, lane_phys;
+      split_mask(*sp, t.mask, &lane, &lane_phys, &reg, &outside);
       PGroup *g = nullptr;
       for (auto &pg : groups) if (pg.lane == lane && pg.reg == reg) { g = &pg; break; }
       if (!g) { groups.push_back(PGroup{lane, reg}); g = &groups.back(); }
@@ -544,7 +599,7 @@ class Planner {
       DGroup g{};
       g.lane_mask = pg.lane; g.reg_mask = pg.reg; g.re = pg.re; g.im = pg.im;
       std::vector<OTerm> loop_terms = pg.multi;
-      for (int shift = kLaneBits; shift < 64 && !pg.single.empty(); shift += 8) {
+      for (int shift = kLaneLow; shift < 64 && !pg.single.empty(); shift += 8) {
         const uint64_t cmask = (shift + 8 >= 64) ? (~0ull << shift) : (((1ull << 8) - 1) << shift);
         std::vector<OTerm> in;
         for (auto &o : pg.single) if (o.mask & cmask) in.push_back(o);
@@ -587,6 +642,8 @@ inline std::string plan_to_json(const std::vector<GateRec> &queue, int nloc, uin
     for (auto &o : sp.ops) (o.kind == OP_DIAG ? ndiag : nd)++;
     std::string rp = "[";
     for (int k = 0; k < sp.rb; ++k) rp += (k ? "," : "") + std::to_string(sp.regpos[k]);
+    rp += "],\"lanehi\":[";
+    for (int k = 0; k < kLaneHi; ++k) rp += (k ? "," : "") + std::to_string(sp.lanehi[k]);
     rp += "]";
     snprintf(buf, sizeof buf,
              "%s{\"gates\":%llu,\"dense_ops\":%d,\"diag_ops\":%d,\"groups\":%zu,\"oterms\":%zu,\"table_entries\":%zu,"

@@ -31,15 +31,16 @@ def _plan(n, ops, g8, shard=None):
   return json.loads(buf.value.decode())
 
 
-def test_qft30_is_five_sweeps_and_accounts_every_gate():
+def test_qft30_is_four_sweeps_and_accounts_every_gate():
   n = 30
   ops, g8 = workloads.qft_stream(range(n)).arrays()
   p = _plan(n, ops, g8)
   sw = p['sweeps']
   S = 16 * 2 ** n
-  assert len(sw) == 5
+  assert len(sw) == 4                           # 11 + 8 + 8 + 3 target bits
   assert sum(s['gates'] for s in sw) + p['noop_gates'] == 465
-  assert sw[0]['regpos'] == [6, 7, 8, 9, 10] and sw[0]['dense_ops'] == 11
+  assert sw[0]['regpos'] == [6, 7, 8, 9, 10] and sw[0]['lanehi'] == [3, 4, 5] and sw[0]['dense_ops'] == 11
+  assert sw[1]['lanehi'] == [11, 12, 13] and sw[1]['regpos'] == [14, 15, 16, 17, 18]   # split-lane tile
   assert all(s['swept_bytes'] == 2 * S for s in sw)            # one read + one write each
   # minimal-touch bytes of BASELINE.md: 30 H x 2S + 435 CU1 x S/2 = 277.5 S
   assert sum(s['alg_bytes'] for s in sw) == int(277.5 * S)
@@ -66,15 +67,16 @@ def test_commutation_rules_keep_order_where_it_matters():
   lack of register bits blocks later gates on its bits."""
   n = 20
   sb = workloads.StreamBuilder()
-  for q in range(7):                       # 7 distinct high targets: only 5 fit one sweep
+  for q in range(10):                      # 10 distinct high targets: only 8 fit one tile
     sb.apply1(gates.hadamard(), q)
-  sb.applyc(gates.pauli_x(), 5, 0)         # dense on qubit 0, control on skipped qubit 5
+  sb.applyc(gates.pauli_x(), 5, 0)         # dense on qubit 0, control on qubit 5
   sb.apply1(gates.hadamard(), 5)
   p = _plan(n, *sb.arrays())
   assert len(p['sweeps']) == 2
+  assert sum(s['gates'] for s in p['sweeps']) == 12
   # the simulation-driven choice keeps qubits 0 and 5 together: H(0) H(5) CX(5->0) H(5)
-  # all run in the first sweep plus three more H; the two left-over H gates follow
-  assert p['sweeps'][0]['gates'] == 7 and p['sweeps'][1]['gates'] == 2
+  # all run in the first sweep plus six more H; the two left-over H gates follow
+  assert p['sweeps'][0]['gates'] == 10 and p['sweeps'][1]['gates'] == 2
   sb = workloads.StreamBuilder()           # order must survive: X then H then X on one qubit,
   for g in (gates.pauli_x(), gates.hadamard(), gates.pauli_x()):  # interleaved with a blocker
     sb.apply1(g, 3)
@@ -100,7 +102,7 @@ def test_supremacy_and_grover_streams_plan_completely():
   ops, g8 = workloads.supremacy_stream(30, 20, seed=0).arrays()
   p = _plan(30, ops, g8)
   assert sum(s['gates'] for s in p['sweeps']) + p['noop_gates'] == len(ops) == 342
-  assert len(p['sweeps']) <= 10
+  assert len(p['sweeps']) <= 8
   ops, g8 = workloads.grover_stream(10, [1, 0] * 5, iterations=1).arrays()
   p = _plan(20, ops, g8)
   assert sum(s['gates'] for s in p['sweeps']) + p['noop_gates'] == len(ops)

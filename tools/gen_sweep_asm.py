@@ -23,7 +23,8 @@ Register map (island-private, declared as clobbers to the compiler), complex128:
 Operands supplied by the C++ kernel:
   %0,%1  tile base address lo,hi (SGPR)      %2  SweepParams* (SGPR pair)
   %3     tile index (idx_high|base) (SGPR pair, for outside-bit predicates)
-  %4     lane*16 (VGPR)  %5 lane (VGPR)  %6,%7 thread index lo,hi (VGPR)
+  %4     this lane's byte offset inside a tile (VGPR)  %5 lane id (VGPR)
+  %6,%7  thread index lo,hi (VGPR)
 Data layouts must match planner.h (SweepOp 96 B, DGroup 64 B, OTerm 24 B) and
 kernels_sweep.hip.h (SweepParams: slot byte offsets at +0x40).
 """
@@ -459,11 +460,8 @@ def gen(rb, wide=True):
   a('s_lshl_b32 s74, s61, 4')
   a('s_add_u32 s98, s48, s74')
   a('s_addc_u32 s99, s49, 0')
-  if DT.wide:
-    a(f'global_load_dwordx4 v[{D_LTAB}:{D_LTAB + 3}], %4, s[98:99]')
-  else:                                          # table entries are 16 B, %4 is lane*8
-    a(f'v_lshlrev_b32 v{V_A}, 1, %4')
-    a(f'global_load_dwordx4 v[{D_LTAB}:{D_LTAB + 3}], v{V_A}, s[98:99]')
+  a(f'v_lshlrev_b32 v{V_A}, 4, %5')             # 16-byte table entries, indexed by the LANE id
+  a(f'global_load_dwordx4 v[{D_LTAB}:{D_LTAB + 3}], v{V_A}, s[98:99]')
   a.label('L_g1')
   a('s_cmp_eq_u32 s62, 0')
   a(f's_cbranch_scc1 {L("L_g2")}')
