@@ -8,5 +8,6 @@ import csv, glob
 f = glob.glob('/tmp/tr/**/t_kernel_trace.csv', recursive=True)[0]
 rows = [r for r in csv.DictReader(open(f)) if 'k_sweep' in r['Kernel_Name']]
 d = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6 for r in rows]
-print('sweeps:', len(d), 'per-step pattern (ms):', [round(x, 2) for x in d[-5:]], 'sum', round(sum(d[-5:]), 2))
+per = len(d) // 4  # warmup + 3 steps
+print('sweeps:', len(d), 'per-step pattern (ms):', [round(x, 2) for x in d[-per:]], 'sum', round(sum(d[-per:]), 2))
 PY
