@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -56,7 +57,28 @@ enum : uint32_t { OP_DENSE_REG = 0, OP_DENSE_LANE = 1, OP_DIAG = 2 };
 // A DIAG op directly followed by an uncontrolled dense op on a LANE bit does not
 // apply its per-lane factor c to the 2^RB slots: the dense op folds it into its
 // per-lane matrix coefficients (H.diag(c)), two complex products per lane.
-enum : uint32_t { OPF_DEFER_C = 1, OPF_USE_C = 2, OPF_REAL = 4 };  // REAL: all four entries real
+enum : uint32_t { OPF_DEFER_C = 1, OPF_USE_C = 2, OPF_REAL = 4,  // REAL: all four entries real
+                  OPF_BFLY = 8, OPF_BFLY_SHIFT = 4 };              // unit-entry butterfly, variant in bits 4..6
+
+// Gates of the form c*M with every entry of M in {1,-1,i,-i} (h, yroot, v = sqrt-x and
+// their adjoints: ops.py:130-132,152-162) cost additions only once the scalar c is moved
+// elsewhere.  Returns the variant (see tools/gen_sweep_asm.py, L_bf) or -1; c = g[0..1].
+inline bool env_flag(const char *name, bool dflt) {
+  const char *e = getenv(name);
+  return e ? atoi(e) != 0 : dflt;
+}
+
+inline int butterfly_variant(const double *g) {
+  const double cr = g[0], ci = g[1];
+  if (cr == 0.0 && ci == 0.0) return -1;
+  auto eq = [&](int k, double r, double i) { return g[2 * k] == r && g[2 * k + 1] == i; };
+  if (eq(1, cr, ci) && eq(2, cr, ci) && eq(3, -cr, -ci)) return 0;     // [[1,1],[1,-1]]
+  if (eq(1, -cr, -ci) && eq(2, cr, ci) && eq(3, cr, ci)) return 1;     // [[1,-1],[1,1]]
+  if (eq(1, cr, ci) && eq(2, -cr, -ci) && eq(3, cr, ci)) return 2;     // [[1,1],[-1,1]]
+  if (eq(1, ci, -cr) && eq(2, ci, -cr) && eq(3, cr, ci)) return 3;     // [[1,-i],[-i,1]]
+  if (eq(1, -ci, cr) && eq(2, -ci, cr) && eq(3, cr, ci)) return 4;     // [[1,i],[i,1]]
+  return -1;
+}
 
 // ---- device-visible records (plain data, copied verbatim to HBM) -------------
 // A factor that multiplies amplitudes whose index has all bits of `mask` set;
@@ -190,6 +212,7 @@ class Planner {
   uint64_t amp_bytes_;
   int rb_cap_;
   bool split_lanes_;   // allow lane bits 3..5 to sit on arbitrary index bits (8 free tile bits)
+  bool butterflies_ = env_flag("QH_BFLY", true);  // unit-entry butterfly ops (settle_butterflies)
   std::vector<uint64_t> alg_override_;
   std::vector<uint32_t> weight_;  // reference gate applications each pending record stands for
 
@@ -432,9 +455,17 @@ class Planner {
     while (popc(common) + rb + kLaneHi > kMaxInsertBits) common &= common - 1;  // the rest stay per-op controls
     rb = std::min(rb, nloc_ - kLaneBits - popc(common));
     sp.fixed_ones = common;
-    // pad the register tile with the lowest free bits (cheap, keeps runs long)
-    for (int p = kLaneLow; p < nloc_ && (int)regs.size() < rb; ++p)
-      if (!((regmask | common | lanemask) >> p & 1ull)) { regs.push_back(p); regmask |= 1ull << p; }
+    // pad the register tile with free bits: 10..13 first (a tile whose spare register
+    // bits sit there streams ~10% faster than with bits 6..9 next to contiguous lanes
+    // or with bits >= 18: tools/geom_scan.py), then the lowest free ones
+    auto pad = [&](int p) {
+      if ((int)regs.size() < rb && p >= kLaneLow && p < nloc_ && !((regmask | common | lanemask) >> p & 1ull)) {
+        regs.push_back(p);
+        regmask |= 1ull << p;
+      }
+    };
+    for (int p = 10; p < 14; ++p) pad(p);
+    for (int p = kLaneLow; p < nloc_; ++p) pad(p);
     std::sort(regs.begin(), regs.end());
     sp.rb = (int)regs.size();
     for (int k = 0; k < sp.rb; ++k) sp.regpos[k] = regs[k];
@@ -509,9 +540,12 @@ class Planner {
         if (li >= 0) { op.kind = OP_DENSE_LANE; op.tb = (uint32_t)li; }
         else { op.kind = OP_DENSE_REG; op.tb = reg_index(*sp, r->tgt); }
         if (r->g[1] == 0.0 && r->g[3] == 0.0 && r->g[5] == 0.0 && r->g[7] == 0.0) op.flags |= OPF_REAL;
+        const bool uncontrolled = op.cm_thread == 0 && op.cm_reg == 0;
+        const int bv = uncontrolled && butterflies_ ? butterfly_variant(r->g) : -1;
+        if (bv >= 0) op.flags |= OPF_BFLY | ((uint32_t)bv << OPF_BFLY_SHIFT);   // settled by settle_butterflies()
         // (for a REAL gate folding would turn its 4-op real path into the 9-op complex
         // one: no gain over applying c to the slots, so only complex gates fold)
-        if (!(op.flags & OPF_REAL) && op.kind == OP_DENSE_LANE && op.cm_thread == 0 && op.cm_reg == 0 && !sp->ops.empty() &&
+        if (!(op.flags & (OPF_REAL | OPF_BFLY)) && op.kind == OP_DENSE_LANE && op.cm_thread == 0 && op.cm_reg == 0 && !sp->ops.empty() &&
             sp->ops.back().kind == OP_DIAG && sp->ops.size() == n_ops_after_flush) {
           sp->ops.back().flags |= OPF_DEFER_C;
           op.flags |= OPF_USE_C;
@@ -533,6 +567,38 @@ class Planner {
       }
     }
     flush_diag(&pending, ~0ull, sp);
+    settle_butterflies(sp);
+  }
+
+  // The scalars c of the butterfly ops are multiplied into ONE uncontrolled dense op of
+  // the sweep (a scalar commutes with everything): the last one, which then runs on the
+  // general path.  Without such a sink nothing is converted.
+  static void settle_butterflies(SweepPlan *sp) {
+    int sink = -1, nbf = 0;
+    for (size_t i = 0; i < sp->ops.size(); ++i) {
+      const SweepOp &o = sp->ops[i];
+      if (o.kind == OP_DIAG || o.cm_thread != 0 || o.cm_reg != 0) continue;
+      sink = (int)i;
+      if (o.flags & OPF_BFLY) nbf++;
+    }
+    const bool sink_is_bf = sink >= 0 && (sp->ops[sink].flags & OPF_BFLY);
+    const bool convert = nbf - (sink_is_bf ? 1 : 0) >= 1;
+    double pr = 1, pi = 0;
+    for (size_t i = 0; i < sp->ops.size(); ++i) {
+      SweepOp &o = sp->ops[i];
+      if (!(o.flags & OPF_BFLY)) continue;
+      if (!convert || (int)i == sink) { o.flags &= ~(OPF_BFLY | (7u << OPF_BFLY_SHIFT)); continue; }
+      cmul_acc(&pr, &pi, o.g[0], o.g[1]);
+      const uint32_t v = (o.flags >> OPF_BFLY_SHIFT) & 7u;
+      memset(o.g, 0, sizeof o.g);
+      if (v == 1) { o.g[0] = -1.0; o.g[1] = 1.0; }        // lane form: new = own + beta*partner,
+      else if (v == 2) { o.g[0] = 1.0; o.g[1] = -1.0; }   // beta on the 0-lane / on the 1-lane
+    }
+    if (!convert) return;
+    SweepOp &o = sp->ops[sink];
+    for (int k = 0; k < 4; ++k) cmul_acc(&o.g[2 * k], &o.g[2 * k + 1], pr, pi);
+    if (o.g[1] == 0.0 && o.g[3] == 0.0 && o.g[5] == 0.0 && o.g[7] == 0.0) o.flags |= OPF_REAL;
+    else o.flags &= ~OPF_REAL;
   }
 
   static void cmul_acc(double *re, double *im, double fr, double fi) {
@@ -638,17 +704,17 @@ inline std::string plan_to_json(const std::vector<GateRec> &queue, int nloc, uin
   char buf[384];
   for (size_t i = 0; i < pr.sweeps.size(); ++i) {
     const SweepPlan &sp = pr.sweeps[i];
-    int nd = 0, ndiag = 0;
-    for (auto &o : sp.ops) (o.kind == OP_DIAG ? ndiag : nd)++;
+    int nd = 0, ndiag = 0, nbf = 0;
+    for (auto &o : sp.ops) { (o.kind == OP_DIAG ? ndiag : nd)++; if (o.flags & OPF_BFLY) nbf++; }
     std::string rp = "[";
     for (int k = 0; k < sp.rb; ++k) rp += (k ? "," : "") + std::to_string(sp.regpos[k]);
     rp += "],\"lanehi\":[";
     for (int k = 0; k < kLaneHi; ++k) rp += (k ? "," : "") + std::to_string(sp.lanehi[k]);
     rp += "]";
     snprintf(buf, sizeof buf,
-             "%s{\"gates\":%llu,\"dense_ops\":%d,\"diag_ops\":%d,\"groups\":%zu,\"oterms\":%zu,\"table_entries\":%zu,"
+             "%s{\"gates\":%llu,\"dense_ops\":%d,\"butterfly_ops\":%d,\"diag_ops\":%d,\"groups\":%zu,\"oterms\":%zu,\"table_entries\":%zu,"
              "\"regpos\":%s,\"fixed_ones\":%llu,\"ntiles\":%llu,\"alg_bytes\":%llu,\"swept_bytes\":%llu}",
-             i ? "," : "", (unsigned long long)sp.gates, nd, ndiag, sp.groups.size(), sp.oterms.size(),
+             i ? "," : "", (unsigned long long)sp.gates, nd, nbf, ndiag, sp.groups.size(), sp.oterms.size(),
              sp.tables.size() / 2, rp.c_str(), (unsigned long long)sp.fixed_ones, (unsigned long long)sp.ntiles,
              (unsigned long long)sp.alg_bytes, (unsigned long long)sp.swept_bytes);
     s += buf;

@@ -333,3 +333,42 @@ def test_complex64_qft_fused_analytic():
     got = st.download()
   want = workloads.qft_analytic(n, x, np.arange(1 << n))
   assert np.max(np.abs(got - want)) < 2e-6 * 5
+
+
+@pytest.mark.parametrize('bw', [128, 64])
+def test_unit_entry_butterflies_vs_oracle(oracle, bw):
+  """h / yroot / v and adjoints run as add-only butterflies inside a sweep (planner.h
+  settle_butterflies, island L_bf*); their scalars land in one other gate.  Every
+  variant on every bit of a 13-qubit state (lane bits, split-lane bits, register
+  bits), next to a general gate, and all-butterfly sweeps (the sink is a butterfly)."""
+  n = 13
+  dt = np.complex128 if bw == 128 else np.complex64
+  rng = np.random.default_rng(99)
+  had, yr, v = gates.hadamard(), gates.yroot(), gates.vgate()
+  variants = [had, yr, np.conj(yr.reshape(2, 2).T), v, np.conj(np.asarray(v).reshape(2, 2).T), -0.3j * np.asarray(had)]
+  streams = []
+  for g in variants:
+    for t in range(n):
+      streams.append([(NO_CTL, t, g), (NO_CTL, (t + 5) % n, gates.rx(0.7)), (NO_CTL, (t + 1) % n, g)])
+  streams.append([(NO_CTL, t, variants[t % 5]) for t in range(n)])          # butterflies only
+  streams.append([(NO_CTL, t, had) for t in range(n)] + [((t + 1) % n, t, gates.u1(0.2 * t)) for t in range(n)] +
+                 [(NO_CTL, t, v) for t in range(n)])
+  worst = 0.0
+  with device.DeviceState(n, bw, fusion=native.QH_FUSE_SWEEP) as st:
+    for stream in streams:
+      psi0 = _rand_state(rng, n, dt)
+      want = psi0.copy()
+      for c, t, g in stream:
+        g = np.asarray(g, dtype=dt).reshape(4)
+        if c == NO_CTL:
+          oracle.apply1(want, g, n, t)
+        else:
+          oracle.applyc(want, g, n, c, t)
+      st.upload(psi0)
+      for c, t, g in stream:
+        if c == NO_CTL:
+          st.apply1(g, t)
+        else:
+          st.applyc(g, c, t)
+      worst = max(worst, float(np.max(np.abs(st.download() - want))))
+  assert worst <= (TOL if bw == 128 else 3e-6), worst

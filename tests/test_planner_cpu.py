@@ -42,6 +42,8 @@ def test_qft30_is_four_sweeps_and_accounts_every_gate():
   assert sw[0]['regpos'] == [6, 7, 8, 9, 10] and sw[0]['lanehi'] == [3, 4, 5] and sw[0]['dense_ops'] == 11
   assert sw[1]['lanehi'] == [11, 12, 13] and sw[1]['regpos'] == [14, 15, 16, 17, 18]   # split-lane tile
   assert all(s['swept_bytes'] == 2 * S for s in sw)            # one read + one write each
+  # all H but one per sweep run as add-only butterflies; the remaining one carries the scalars
+  assert [s['butterfly_ops'] for s in sw] == [s['dense_ops'] - 1 for s in sw]
   # minimal-touch bytes of BASELINE.md: 30 H x 2S + 435 CU1 x S/2 = 277.5 S
   assert sum(s['alg_bytes'] for s in sw) == int(277.5 * S)
   # lazy diagonal placement + tables: no per-gate loop terms left in the big sweep

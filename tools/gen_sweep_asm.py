@@ -75,6 +75,13 @@ def MOV():
   return 'v_mov_b64' if DT.wide else 'v_mov_b32'
 
 
+def ADDS(d, x, y, neg=False):
+  """d = x + y (neg: d = x - y)."""
+  if DT.wide:
+    return f'v_add_f64 {d}, {x}, {"-" if neg else ""}{y}'
+  return f'{"v_sub_f32" if neg else "v_add_f32"} {d}, {x}, {y}'
+
+
 class Asm:
   def __init__(self):
     self.lines = []
@@ -169,6 +176,8 @@ def gen(rb, wide=True):
   a('s_waitcnt lgkmcnt(0)')
   a('s_cmp_eq_u32 s44, 2')
   a(f's_cbranch_scc1 {L("L_diag")}')
+  a('s_bitcmp1_b32 s51, 3')                   # OPF_BFLY: uncontrolled unit-entry butterfly
+  a(f's_cbranch_scc1 {L("L_bf")}')
   # control predicate of this thread: (it & cm_thread) == cm_thread  -> s[68:69]
   a(f'v_and_b32 v{V_A}, s48, %6')
   a(f'v_and_b32 v{V_B}, s49, %7')
@@ -315,6 +324,133 @@ def gen(rb, wide=True):
     a(FMA() + f' {X(k)}, {rcb}, {V2(buf)}, {X(k)}')
     a(FMA() + f' {Y(k)}, {rcb}, {V2(buf + W())}, {Y(k)}')
   a(f's_branch {L("L_next")}')
+
+
+  # ---- unit-entry butterflies (OPF_BFLY): the gate is c*M with M's entries in {1,-1,i,-i};
+  # the planner moved c into another op of the sweep, so M costs adds only, in place.
+  #   variant (flags bits 4..6): 0  [[1, 1],[ 1,-1]]  (h)        1  [[1,-1],[1,1]]  (yroot)
+  #   2  [[1,1],[-1,1]] (yroot^+)   3  [[1,-i],[-i,1]] (v, sqrt-x)   4  [[1,i],[i,1]] (v^+)
+  a.label('L_bf')
+  a('s_bfe_u32 s74, s51, 0x30004')
+  a('s_cmp_eq_u32 s44, 1')
+  a(f's_cbranch_scc1 {L("L_bfl")}')
+  for v in range(5):
+    a(f's_cmp_eq_u32 s74, {v}')
+    a(f's_cbranch_scc1 {L(f"L_bfv{v}")}')
+  a(f's_branch {L("L_next")}')
+  for v in range(5):
+    a.label(f'L_bfv{v}')
+    for b in range(rb):
+      a(f's_cmp_eq_u32 s45, {b}')
+      a(f's_cbranch_scc1 {L(f"L_bf{v}_{b}")}')
+    a(f's_branch {L("L_next")}')
+  for v in range(5):
+    for b in range(rb):
+      a.label(f'L_bf{v}_{b}')
+      pairs = []
+      for h in range(nr // 2):
+        k0 = ((h >> b) << (b + 1)) | (h & ((1 << b) - 1))
+        pairs.append((k0, k0 | (1 << b)))
+      for i in range(0, len(pairs), 4):           # four pairs interleaved: 8 independent chains
+        grp = pairs[i:i + 4]
+        if v == 0:      # a' = a + b ; b' = a - b = a' - 2b
+          for k0, k1 in grp:
+            a(ADDS(X(k0), X(k0), X(k1)))
+            a(ADDS(Y(k0), Y(k0), Y(k1)))
+          for k0, k1 in grp:
+            a(FMA() + f' {X(k1)}, -2.0, {X(k1)}, {X(k0)}')
+            a(FMA() + f' {Y(k1)}, -2.0, {Y(k1)}, {Y(k0)}')
+        elif v == 1:    # a' = a - b ; b' = a + b = a' + 2b
+          for k0, k1 in grp:
+            a(ADDS(X(k0), X(k0), X(k1), neg=True))
+            a(ADDS(Y(k0), Y(k0), Y(k1), neg=True))
+          for k0, k1 in grp:
+            a(FMA() + f' {X(k1)}, 2.0, {X(k1)}, {X(k0)}')
+            a(FMA() + f' {Y(k1)}, 2.0, {Y(k1)}, {Y(k0)}')
+        elif v == 2:    # a' = a + b ; b' = b - a = 2b - a'
+          for k0, k1 in grp:
+            a(ADDS(X(k0), X(k0), X(k1)))
+            a(ADDS(Y(k0), Y(k0), Y(k1)))
+          for k0, k1 in grp:
+            a(FMA() + f' {X(k1)}, 2.0, {X(k1)}, -{X(k0)}')
+            a(FMA() + f' {Y(k1)}, 2.0, {Y(k1)}, -{Y(k0)}')
+        elif v == 3:    # a' = a - i b ; b' = b - i a
+          for k0, k1 in grp:
+            a(ADDS(X(k0), X(k0), Y(k1)))              # ar' = ar + bi
+            a(ADDS(Y(k0), Y(k0), X(k1), neg=True))    # ai' = ai - br
+          for k0, k1 in grp:
+            a(FMA() + f' {Y(k1)}, 2.0, {Y(k1)}, -{X(k0)}')   # bi' = bi - ar = 2bi - ar'
+            a(FMA() + f' {X(k1)}, 2.0, {X(k1)}, {Y(k0)}')    # br' = br + ai = 2br + ai'
+        else:           # a' = a + i b ; b' = b + i a
+          for k0, k1 in grp:
+            a(ADDS(X(k0), X(k0), Y(k1), neg=True))    # ar' = ar - bi
+            a(ADDS(Y(k0), Y(k0), X(k1)))              # ai' = ai + br
+          for k0, k1 in grp:
+            a(FMA() + f' {Y(k1)}, 2.0, {Y(k1)}, {X(k0)}')    # bi' = bi + ar = 2bi + ar'
+            a(FMA() + f' {X(k1)}, 2.0, {X(k1)}, -{Y(k0)}')   # br' = br - ai = 2br - ai'
+      a(f's_branch {L("L_next")}')
+  # lane bit: partner p via ds_bpermute, own value o
+  a.label('L_bfl')
+  a('s_lshl_b32 s75, 1, s45')
+  a(f'v_xor_b32 v{LN_ADDR}, s75, %5')
+  a(f'v_lshlrev_b32 v{LN_ADDR}, 2, v{LN_ADDR}')
+  a(f'v_and_b32 v{LN_TMP}, s75, %5')
+  a(f'v_cmp_ne_u32 vcc, 0, v{LN_TMP}')           # this lane holds the "1" element of the pair
+  coef = V2(LN_COEF['car'])
+  for v, lab in ((0, 'L_bfl_a'), (1, 'L_bfl_b'), (2, 'L_bfl_b'), (3, 'L_bfl_v'), (4, 'L_bfl_w')):
+    a(f's_cmp_eq_u32 s74, {v}')
+    a(f's_cbranch_scc1 {L(lab)}')
+  a(f's_branch {L("L_next")}')
+
+  def bf_lane(form):
+    shuf_r(0, LN_BUF[0])
+    for k in range(nr):
+      if k + 1 < nr:
+        shuf_r(k + 1, LN_BUF[(k + 1) & 1])
+        a(f's_waitcnt lgkmcnt({2 * W()})')
+      else:
+        a('s_waitcnt lgkmcnt(0)')
+      pr, pi = V2(LN_BUF[k & 1]), V2(LN_BUF[k & 1] + W())
+      if form == 'a':      # new = alpha*o + p
+        a(FMA() + f' {X(k)}, {coef}, {X(k)}, {pr}')
+        a(FMA() + f' {Y(k)}, {coef}, {Y(k)}, {pi}')
+      elif form == 'b':    # new = o + beta*p
+        a(FMA() + f' {X(k)}, {coef}, {pr}, {X(k)}')
+        a(FMA() + f' {Y(k)}, {coef}, {pi}, {Y(k)}')
+      elif form == 'v':    # new = o - i p
+        a(ADDS(X(k), X(k), pi))
+        a(ADDS(Y(k), Y(k), pr, neg=True))
+      else:                # new = o + i p
+        a(ADDS(X(k), X(k), pi, neg=True))
+        a(ADDS(Y(k), Y(k), pr))
+    a(f's_branch {L("L_next")}')
+
+  c0 = LN_COEF['car']
+  a.label('L_bfl_a')                               # h: alpha = +1 on the 0-lane, -1 on the 1-lane
+  if DT.wide:
+    a(f'v_mov_b32 v{c0}, 0')
+    a(f'v_mov_b32 v{c0 + 1}, 0x3ff00000')
+    a(f'v_mov_b32 v{LN_TMP}, 0xbff00000')
+    a(f'v_cndmask_b32 v{c0 + 1}, v{c0 + 1}, v{LN_TMP}, vcc')
+  else:
+    a(f'v_mov_b32 v{LN_TMP}, -1.0')
+    a(f'v_cndmask_b32 v{c0}, 1.0, v{LN_TMP}, vcc')
+  bf_lane('a')
+  a.label('L_bfl_b')                               # yroot / yroot^+: beta = g[0] on the 0-lane, g[1] on the 1-lane
+  if DT.wide:
+    for d in range(2):
+      a(f'v_mov_b32 v{c0 + d}, s{52 + d}')
+      a(f'v_mov_b32 v{LN_TMP}, s{54 + d}')
+      a(f'v_cndmask_b32 v{c0 + d}, v{c0 + d}, v{LN_TMP}, vcc')
+  else:
+    a(f'v_cvt_f32_f64 v{c0}, s[52:53]')
+    a(f'v_cvt_f32_f64 v{LN_TMP}, s[54:55]')
+    a(f'v_cndmask_b32 v{c0}, v{c0}, v{LN_TMP}, vcc')
+  bf_lane('b')
+  a.label('L_bfl_v')
+  bf_lane('v')
+  a.label('L_bfl_w')
+  bf_lane('w')
 
   # ---- dense 2x2 on a lane bit: partner via ds_bpermute -------------------------------
   a.label('L_lane')

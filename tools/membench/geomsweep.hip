@@ -1,0 +1,68 @@
+// geomsweep.hip -- HBM rate of a read-modify-write register-tile sweep as a function of the
+// tile geometry alone: lane bits {0,1,2} + three arbitrary "high" lane bits + five arbitrary
+// register bits (the k_sweep<5> access pattern with a trivial body).
+//   usage: geomsweep NBITS  l3,l4,l5,r0,r1,r2,r3,r4  [more geometries ...]
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
+
+typedef double v2d __attribute__((ext_vector_type(2)));
+struct Geom { int pos[8]; int sorted[8]; };
+
+__global__ __launch_bounds__(256) void k_geom(v2d *__restrict__ p, uint64_t ntiles, Geom g) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint64_t loff = (uint64_t)(lane & 7);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) loff |= (uint64_t)((lane >> (3 + k)) & 1) << g.pos[k];
+  const uint64_t w = (uint64_t)blockIdx.x * 4 + wave;
+  if (w >= ntiles) return;
+  uint64_t j = w << 3;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {           // insert a zero at each tile bit, ascending
+    const uint64_t low = (1ull << g.sorted[k]) - 1;
+    j = ((j & ~low) << 1) | (j & low);
+  }
+  v2d a[32];
+#pragma unroll
+  for (int k = 0; k < 32; ++k) {
+    uint64_t o = 0;
+#pragma unroll
+    for (int b = 0; b < 5; ++b) o |= (uint64_t)((k >> b) & 1) << g.pos[3 + b];
+    a[k] = __builtin_nontemporal_load(&p[(j | o) + loff]);
+  }
+#pragma unroll
+  for (int k = 0; k < 32; ++k) {
+    uint64_t o = 0;
+#pragma unroll
+    for (int b = 0; b < 5; ++b) o |= (uint64_t)((k >> b) & 1) << g.pos[3 + b];
+    v2d t; t.x = a[k].x * 0.6 - a[k].y * 0.8; t.y = a[k].x * 0.8 + a[k].y * 0.6;
+    __builtin_nontemporal_store(t, &p[(j | o) + loff]);
+  }
+}
+
+int main(int argc, char **argv) {
+  int nb = argc > 1 ? atoi(argv[1]) : 30;
+  uint64_t n = 1ull << nb; size_t bytes = n * 16;
+  v2d *p; CK(hipMalloc(&p, bytes)); CK(hipMemset(p, 0, bytes));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  uint64_t ntiles = n >> 11;
+  for (int a = 2; a < argc; ++a) {
+    Geom g; int k = 0;
+    char buf[256]; strncpy(buf, argv[a], 255); buf[255] = 0;
+    for (char *t = strtok(buf, ","); t && k < 8; t = strtok(nullptr, ",")) g.pos[k++] = atoi(t);
+    if (k != 8) { printf("bad geometry %s\n", argv[a]); continue; }
+    memcpy(g.sorted, g.pos, sizeof(g.pos)); std::sort(g.sorted, g.sorted + 8);
+    float best = 1e9f;
+    for (int rep = 0; rep < 4; ++rep) {
+      CK(hipEventRecord(e0));
+      k_geom<<<dim3((unsigned)((ntiles + 3) / 4)), dim3(256)>>>(p, ntiles, g);
+      CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (rep && ms < best) best = ms;
+    }
+    printf("%s  %.3f ms  %.0f GB/s\n", argv[a], best, 2.0 * bytes / best / 1e6);
+  }
+  return 0;
+}
