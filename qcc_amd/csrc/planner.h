@@ -212,7 +212,8 @@ class Planner {
   uint64_t amp_bytes_;
   int rb_cap_;
   bool split_lanes_;   // allow lane bits 3..5 to sit on arbitrary index bits (8 free tile bits)
-  bool butterflies_ = env_flag("QH_BFLY", true);  // unit-entry butterfly ops (settle_butterflies)
+  bool butterflies_ = env_flag("QH_BFLY", true);
+  bool defer_diag_ = env_flag("QH_DEFER_DIAG", true);   // see build_sweep  // unit-entry butterfly ops (settle_butterflies)
   std::vector<uint64_t> alg_override_;
   std::vector<uint32_t> weight_;  // reference gate applications each pending record stands for
 
@@ -402,6 +403,22 @@ class Planner {
     const uint64_t lanemask = always | mask_of(lanehi);
     std::vector<uint8_t> flags(pending.size(), 0);
     pass(pending, lanemask | regmask, pending.size(), &flags);
+    // A diagonal gate that no dense op of THIS sweep waits for, but a dense gate of a later
+    // sweep does, is left for that sweep: there its factor joins the group that is applied
+    // in front of that dense op anyway (one more table factor), instead of costing a group
+    // of its own here.  (Leaving it is legal: it commutes with everything taken after it.)
+    if (defer_diag_) {
+      uint64_t future = 0, later_targets = 0;
+      for (size_t i = 0; i < pending.size(); ++i)
+        if (!flags[i] && !plan_diag(pending[i].g, pending[i].tgt) && pending[i].tgt >= 0) future |= 1ull << pending[i].tgt;
+      for (size_t i = pending.size(); i-- > 0;) {
+        if (!flags[i]) continue;
+        const GateRec &r = pending[i];
+        if (!plan_diag(r.g, r.tgt)) { later_targets |= 1ull << r.tgt; continue; }
+        const uint64_t bits = r.ctl_mask | (r.tgt >= 0 ? (1ull << r.tgt) : 0);
+        if (!(bits & later_targets) && (bits & future)) flags[i] = 0;
+      }
+    }
     std::vector<const GateRec *> taken;
     bool any_dense = false;
     for (size_t i = 0; i < pending.size(); ++i) {
@@ -634,36 +651,9 @@ class Planner {
     SweepOp op{};
     op.kind = OP_DIAG;
     op.group_off = (uint32_t)sp->groups.size();
-    // (1) pure-lane groups (no outside terms) with equal reg_mask merge into one lane table
-    std::vector<bool> done(groups.size(), false);
-    for (size_t i = 0; i < groups.size(); ++i) {
-      if (done[i] || !groups[i].single.empty() || !groups[i].multi.empty()) continue;
-      std::vector<size_t> same;
-      for (size_t j = i; j < groups.size(); ++j)
-        if (!done[j] && groups[j].reg == groups[i].reg && groups[j].single.empty() && groups[j].multi.empty())
-          same.push_back(j);
-      if (same.size() < 2) continue;
-      DGroup g{};
-      g.reg_mask = groups[i].reg;
-      g.re = 1; g.im = 0;
-      g.flags = DG_LTAB;
-      g.ltab_off = (uint32_t)(sp->tables.size() / 2);
-      for (uint32_t lane = 0; lane < 64; ++lane) {
-        double fr = 1, fi = 0;
-        for (size_t j : same)
-          if ((lane & groups[j].lane) == groups[j].lane) cmul_acc(&fr, &fi, groups[j].re, groups[j].im);
-        sp->tables.push_back(fr);
-        sp->tables.push_back(fi);
-      }
-      for (size_t j : same) done[j] = true;
-      sp->groups.push_back(g);
-    }
-    // (2) the rest: one DGroup each; single-bit outside factors become chunk tables
-    for (size_t i = 0; i < groups.size(); ++i) {
-      if (done[i]) continue;
-      PGroup &pg = groups[i];
-      DGroup g{};
-      g.lane_mask = pg.lane; g.reg_mask = pg.reg; g.re = pg.re; g.im = pg.im;
+    // single-bit outside factors of a group become 256-entry chunk tables (one scalar
+    // load per 8 index bits at run time); the rest stay loop terms
+    auto attach_outside = [&](DGroup &g, PGroup &pg) {
       std::vector<OTerm> loop_terms = pg.multi;
       for (int shift = kLaneLow; shift < 64 && !pg.single.empty(); shift += 8) {
         const uint64_t cmask = (shift + 8 >= 64) ? (~0ull << shift) : (((1ull << 8) - 1) << shift);
@@ -688,6 +678,49 @@ class Planner {
       g.oterm_off = (uint32_t)sp->oterms.size();
       g.n_oterms = (uint32_t)loop_terms.size();
       for (auto &o : loop_terms) sp->oterms.push_back(o);
+    };
+    // (1) groups with equal reg_mask whose factor depends on the lane only merge into ONE
+    // lane table; the wave-uniform group of the same reg_mask (lane_mask 0: constant and
+    // outside-bit factors) rides along, so the slots are multiplied once: f = ltab[lane]*u
+    std::vector<bool> done(groups.size(), false);
+    for (size_t i = 0; i < groups.size(); ++i) {
+      if (done[i]) continue;
+      std::vector<size_t> lane_only;
+      int uniform = -1;
+      for (size_t j = i; j < groups.size(); ++j) {
+        if (done[j] || groups[j].reg != groups[i].reg) continue;
+        const bool has_out = !groups[j].single.empty() || !groups[j].multi.empty();
+        if (!has_out && groups[j].lane != 0) lane_only.push_back(j);
+        else if (groups[j].lane == 0) uniform = (int)j;
+      }
+      if (lane_only.empty() || lane_only.size() + (uniform >= 0 ? 1 : 0) < 2) continue;
+      DGroup g{};
+      g.reg_mask = groups[i].reg;
+      g.re = 1; g.im = 0;
+      g.flags = DG_LTAB;
+      g.ltab_off = (uint32_t)(sp->tables.size() / 2);
+      for (uint32_t lane = 0; lane < 64; ++lane) {
+        double fr = 1, fi = 0;
+        for (size_t j : lane_only)
+          if ((lane & groups[j].lane) == groups[j].lane) cmul_acc(&fr, &fi, groups[j].re, groups[j].im);
+        sp->tables.push_back(fr);
+        sp->tables.push_back(fi);
+      }
+      for (size_t j : lane_only) done[j] = true;
+      if (uniform >= 0) {
+        g.re = groups[uniform].re; g.im = groups[uniform].im;
+        attach_outside(g, groups[uniform]);
+        done[uniform] = true;
+      }
+      sp->groups.push_back(g);
+    }
+    // (2) the rest: one DGroup each
+    for (size_t i = 0; i < groups.size(); ++i) {
+      if (done[i]) continue;
+      PGroup &pg = groups[i];
+      DGroup g{};
+      g.lane_mask = pg.lane; g.reg_mask = pg.reg; g.re = pg.re; g.im = pg.im;
+      attach_outside(g, pg);
       sp->groups.push_back(g);
     }
     op.n_groups = (uint32_t)(sp->groups.size() - op.group_off);
@@ -718,6 +751,23 @@ inline std::string plan_to_json(const std::vector<GateRec> &queue, int nloc, uin
              sp.tables.size() / 2, rp.c_str(), (unsigned long long)sp.fixed_ones, (unsigned long long)sp.ntiles,
              (unsigned long long)sp.alg_bytes, (unsigned long long)sp.swept_bytes);
     s += buf;
+    if (env_flag("QH_PLAN_VERBOSE", false)) {   // op list for tools/plan_dump.py (debugging aid)
+      s.pop_back();
+      s += ",\"ops\":[";
+      for (size_t k = 0; k < sp.ops.size(); ++k) {
+        const SweepOp &o = sp.ops[k];
+        snprintf(buf, sizeof buf, "%s{\"kind\":%u,\"tb\":%u,\"flags\":%u,\"cm_reg\":%u,\"cm_thread\":%llu,\"groups\":[",
+                 k ? "," : "", o.kind, o.tb, o.flags, o.cm_reg, (unsigned long long)o.cm_thread);
+        s += buf;
+        for (uint32_t gi = 0; o.kind == OP_DIAG && gi < o.n_groups; ++gi) {
+          const DGroup &g = sp.groups[o.group_off + gi];
+          snprintf(buf, sizeof buf, "%s[%u,%u,%u,%u,%u]", gi ? "," : "", g.lane_mask, g.reg_mask, g.flags, g.ntab, g.n_oterms);
+          s += buf;
+        }
+        s += "]}";
+      }
+      s += "]}";
+    }
   }
   s += "]}";
   return s;
