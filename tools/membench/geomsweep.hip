@@ -10,14 +10,20 @@
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 
 typedef double v2d __attribute__((ext_vector_type(2)));
-struct Geom { int pos[8]; int sorted[8]; };
+struct Geom { int pos[8]; int sorted[8]; int rot; int nblk_bits; };
 
 __global__ __launch_bounds__(256) void k_geom(v2d *__restrict__ p, uint64_t ntiles, Geom g) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint64_t loff = (uint64_t)(lane & 7);
 #pragma unroll
   for (int k = 0; k < 3; ++k) loff |= (uint64_t)((lane >> (3 + k)) & 1) << g.pos[k];
-  const uint64_t w = (uint64_t)blockIdx.x * 4 + wave;
+  // optional rotation of the block index: the fastest-varying block bits land on the HIGHEST free bits
+  uint64_t bi = blockIdx.x;
+  if (g.rot) {
+    const uint64_t m = (1ull << g.nblk_bits) - 1;
+    bi = ((bi >> g.rot) | (bi << (g.nblk_bits - g.rot))) & m;
+  }
+  const uint64_t w = bi * 4 + wave;
   if (w >= ntiles) return;
   uint64_t j = w << 3;
 #pragma unroll
@@ -53,6 +59,8 @@ int main(int argc, char **argv) {
     Geom g; int k = 0;
     char buf[256]; strncpy(buf, argv[a], 255); buf[255] = 0;
     for (char *t = strtok(buf, ","); t && k < 8; t = strtok(nullptr, ",")) g.pos[k++] = atoi(t);
+    g.rot = 0; g.nblk_bits = nb - 13;
+    if (k == 8) { char *c = strchr(argv[a], ':'); if (c) g.rot = atoi(c + 1); }
     if (k != 8) { printf("bad geometry %s\n", argv[a]); continue; }
     memcpy(g.sorted, g.pos, sizeof(g.pos)); std::sort(g.sorted, g.sorted + 8);
     float best = 1e9f;
