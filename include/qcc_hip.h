@@ -88,6 +88,14 @@ int qh_nbits(qh_handle h, int *nbits_local, int *nbits_global);
 /* ---- initialisation and host <-> device --------------------------------- */
 /* |index> in global logical index space (zero elsewhere).                    */
 int qh_init_basis(qh_handle h, uint64_t index);
+/* Product state f_0 (x) f_1 (x) ... (x) f_{k-1} (np.kron order: f_0 on the most significant
+ * qubits), built on the device -- what qc.reg/qubit/bitstring/state() build with
+ * np.kron on the host (src/lib/circuit.py:121-164, state.py:185-246).
+ * Factor j spans nq[j] qubits (sum == nbits_global) and is a table of 2^nq[j]
+ * complex128 amplitudes (amps[j], interleaved re,im; nq[j] <= 24) or, where amps is NULL
+ * or amps[j] is NULL, the basis state |basis[j]>.  At most 32 factors.           */
+int qh_init_product(qh_handle h, int nfactors, const int *nq, const double *const *amps,
+                    const uint64_t *basis);
 /* offset/count in amplitudes of the LOCAL shard, physical order.             */
 int qh_upload(qh_handle h, const void *host, uint64_t offset, uint64_t count);
 int qh_download(qh_handle h, void *host, uint64_t offset, uint64_t count);

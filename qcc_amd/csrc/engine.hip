@@ -550,6 +550,67 @@ int qh_init_basis(qh_handle h, uint64_t index) {
   return check_launch(h);
 }
 
+int qh_init_product(qh_handle h, int nfactors, const int *nq, const double *const *amps, const uint64_t *basis) {
+  if (!h || !nq || nfactors < 1) return fail(QH_ERR_ARG, "null handle / no factors");
+  if (nfactors > qh::kMaxFactors) return fail(QH_ERR_ARG, "too many factors (merge small ones on the host)");
+  qh::ProductSpec sp{};
+  sp.nf = nfactors;
+  sp.nglob = h->nglob;
+  sp.identity = 1;
+  for (int b = 0; b < h->nglob; ++b) {
+    sp.perm[b] = (uint8_t)h->perm[b];
+    if (h->perm[b] != b) sp.identity = 0;
+  }
+  int total = 0;
+  uint64_t entries = 0;
+  for (int f = 0; f < nfactors; ++f) {
+    if (nq[f] < 1 || nq[f] > 63) return fail(QH_ERR_ARG, "factor size out of range");
+    total += nq[f];
+    const bool is_basis = !amps || !amps[f];
+    if (is_basis && !basis) return fail(QH_ERR_ARG, "basis factor without basis[]");
+    if (is_basis && (basis[f] >> nq[f])) return fail(QH_ERR_ARG, "basis index out of range");
+    if (!is_basis) {
+      if (nq[f] > 24) return fail(QH_ERR_ARG, "table factor larger than 2^24 amplitudes");
+      entries += 1ull << nq[f];
+    }
+  }
+  if (total != h->nglob) return fail(QH_ERR_ARG, "factor sizes do not add up to the number of qubits");
+  if (entries > (1ull << 25)) return fail(QH_ERR_ARG, "factor tables larger than 2^25 amplitudes");
+  h->queue.clear();
+  if (h->dry) return QH_OK;
+  std::vector<double> tab(2 * std::max<uint64_t>(entries, 1));
+  uint64_t off = 0;
+  int shift = h->nglob;
+  for (int f = 0; f < nfactors; ++f) {   // f_0 holds the most significant qubits (np.kron order)
+    shift -= nq[f];
+    sp.shift[f] = (uint8_t)shift;
+    sp.nq[f] = (uint8_t)nq[f];
+    sp.is_basis[f] = (!amps || !amps[f]) ? 1 : 0;
+    if (sp.is_basis[f]) { sp.basis[f] = basis[f]; continue; }
+    sp.off[f] = (uint32_t)off;
+    memcpy(&tab[2 * off], amps[f], (size_t)16 << nq[f]);
+    off += 1ull << nq[f];
+  }
+  HIP_TRY(hipSetDevice(h->device));
+  double2 *d_tab = nullptr;
+  HIP_TRY(hipMalloc((void **)&d_tab, tab.size() * sizeof(double)));
+  hipError_t e = hipMemcpyAsync(d_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, h->stream);
+  if (e == hipSuccess) {
+    const uint64_t n = 1ull << h->nloc;
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    const uint64_t idx_high = h->shard << h->nloc;
+    if (h->bw == 128)
+      hipLaunchKernelGGL(qh::k_init_product<double>, grid, block, 0, h->stream, (double2 *)h->d_psi, n, idx_high, sp, d_tab);
+    else
+      hipLaunchKernelGGL(qh::k_init_product<float>, grid, block, 0, h->stream, (float2 *)h->d_psi, n, idx_high, sp, d_tab);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);   // `tab` and d_tab are released below
+  }
+  (void)hipFree(d_tab);
+  if (e != hipSuccess) return fail(QH_ERR_HIP, hipGetErrorString(e));
+  return QH_OK;
+}
+
 int qh_upload(qh_handle h, const void *host, uint64_t offset, uint64_t count) {
   if (!h || !host || h->dry) return fail(QH_ERR_ARG, "null/dry");
   if (offset + count > (1ull << h->nloc)) return fail(QH_ERR_ARG, "upload range out of bounds");

@@ -173,6 +173,52 @@ __global__ void k_set_one(typename AmpT<R>::type *psi, uint64_t index) {
   psi[index] = one;
 }
 
+// Product state f_0 (x) ... (x) f_{k-1} written in place (circuit.py:121-164
+// builds it with np.kron on the host).  Every amplitude is the product of one entry per
+// factor; a factor is a table of complex128 values or a basis state (entry 1 at `basis`).
+constexpr int kMaxFactors = 32;
+struct ProductSpec {
+  int nf;
+  int identity;               // physical bit == logical bit (no remap since creation)
+  int nglob;
+  uint8_t shift[kMaxFactors]; // lowest LOGICAL bit of the factor
+  uint8_t nq[kMaxFactors];
+  uint8_t is_basis[kMaxFactors];
+  uint32_t off[kMaxFactors];  // first table entry (complex128 units)
+  uint64_t basis[kMaxFactors];
+  uint8_t perm[64];           // physical bit of logical bit
+};
+
+template <typename R>
+__global__ __launch_bounds__(256) void k_init_product(typename AmpT<R>::type *__restrict__ psi, uint64_t n,
+                                                      uint64_t idx_high, ProductSpec sp,
+                                                      const double2 *__restrict__ tab) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint64_t logical = idx_high | i;
+  if (!sp.identity) {
+    const uint64_t phys = logical;
+    logical = 0;
+    for (int b = 0; b < sp.nglob; ++b) logical |= ((phys >> sp.perm[b]) & 1ull) << b;
+  }
+  double re = 1.0, im = 0.0;
+  for (int f = 0; f < sp.nf; ++f) {
+    const uint64_t v = (logical >> sp.shift[f]) & ((sp.nq[f] >= 64) ? ~0ull : ((1ull << sp.nq[f]) - 1ull));
+    if (sp.is_basis[f]) {
+      if (v != sp.basis[f]) { re = 0.0; im = 0.0; break; }
+    } else {
+      const double2 t = tab[sp.off[f] + v];
+      const double nr = re * t.x - im * t.y;
+      im = re * t.y + im * t.x;
+      re = nr;
+    }
+  }
+  typename AmpT<R>::type a;
+  a.x = (R)re;
+  a.y = (R)im;
+  st_amp<true>(psi + i, a);
+}
+
 // ---- readers ----------------------------------------------------
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

@@ -68,6 +68,11 @@ inline bool env_flag(const char *name, bool dflt) {
   return e ? atoi(e) != 0 : dflt;
 }
 
+inline int env_int(const char *name, int dflt) {
+  const char *e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
 inline int butterfly_variant(const double *g) {
   const double cr = g[0], ci = g[1];
   if (cr == 0.0 && ci == 0.0) return -1;
@@ -213,6 +218,7 @@ class Planner {
   int rb_cap_;
   bool split_lanes_;   // allow lane bits 3..5 to sit on arbitrary index bits (8 free tile bits)
   bool butterflies_ = env_flag("QH_BFLY", true);
+  size_t dense_weight_ = env_int("QH_PLAN_DENSE_W", 1);  // score of a dense gate when choosing tile bits (diagonal = 1)
   bool defer_diag_ = env_flag("QH_DEFER_DIAG", true);   // see build_sweep  // unit-entry butterfly ops (settle_butterflies)
   std::vector<uint64_t> alg_override_;
   std::vector<uint32_t> weight_;  // reference gate applications each pending record stands for
@@ -308,7 +314,7 @@ class Planner {
               std::vector<uint8_t> *taken_flags) const {
     uint64_t blocked_all = 0;    // bits a skipped gate acts densely on
     uint64_t blocked_diag = 0;   // bits a skipped gate acts diagonally on
-    size_t count = 0;
+    size_t count = 0, score = 0;
     const size_t n = std::min(window, pending.size());
     for (size_t i = 0; i < n; ++i) {
       const GateRec &r = pending[i];
@@ -321,6 +327,7 @@ class Planner {
                         (diag || ((tilemask >> r.tgt) & 1ull));
       if (can_pass && fits) {
         ++count;
+        score += diag ? 1 : dense_weight_;
         if (taken_flags) (*taken_flags)[i] = 1;
       } else {
         blocked_all |= dense_bits;
@@ -329,7 +336,7 @@ class Planner {
         // local bits are blocked densely nothing further can pass
       }
     }
-    return count;
+    return score;
   }
 
   // Tile = index bits {0,1,2} (always) + 3 "lane-high" bits + up to 5 register bits.

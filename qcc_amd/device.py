@@ -21,6 +21,45 @@ def _g8(gate):
   return g, g.ctypes.data_as(_dp)
 
 
+def merge_factors(factors, table_bits=12, max_factors=32):
+  """Adjacent factors are merged on the host while that is cheap (basis with basis;
+  tables up to 2^table_bits amplitudes), so that the device sees few factors."""
+  out = []
+  for n, x in factors:
+    n = int(n)
+    if n == 0:
+      continue
+    is_int = isinstance(x, (int, np.integer))
+    if out:
+      pn, px = out[-1]
+      p_int = isinstance(px, (int, np.integer))
+      if is_int and p_int and pn + n <= 63:
+        out[-1] = (pn + n, (int(px) << n) | int(x))
+        continue
+      if not (is_int and p_int) and pn + n <= table_bits:
+        def table(m, v):
+          if isinstance(v, (int, np.integer)):
+            t = np.zeros(1 << m, dtype=np.complex128)
+            t[int(v)] = 1
+            return t
+          return np.asarray(v, dtype=np.complex128).reshape(-1)
+        out[-1] = (pn + n, np.kron(table(pn, px), table(n, x)))
+        continue
+    out.append((n, int(x) if is_int else np.asarray(x, dtype=np.complex128).reshape(-1)))
+  while len(out) > max_factors:      # pathological: many large tables; merge the smallest neighbours
+    sizes = [out[i][0] + out[i + 1][0] for i in range(len(out) - 1)]
+    i = int(np.argmin(sizes))
+    (n0, x0), (n1, x1) = out[i], out[i + 1]
+    def tab(m, v):
+      if isinstance(v, (int, np.integer)):
+        t = np.zeros(1 << m, dtype=np.complex128)
+        t[int(v)] = 1
+        return t
+      return v
+    out[i:i + 2] = [(n0 + n1, np.kron(tab(n0, x0), tab(n1, x1)))]
+  return out
+
+
 class DeviceState:
   """Owns a qh_handle.  complex128 (bit_width=128) or complex64 (64)."""
 
@@ -77,6 +116,26 @@ class DeviceState:
   # -- initialisation / IO ------------------------------------------------------
   def init_basis(self, index=0):
     native.check(self.lib.qh_init_basis(self.h, int(index)))
+
+  def init_product(self, factors):
+    """State := f_0 (x) f_1 (x) ... built on the device.  factors: [(nqubits, x)], x an
+    int (basis state |x>) or 2^nqubits amplitudes; f_0 holds the most significant qubits."""
+    factors = merge_factors(factors)
+    k = len(factors)
+    nq = (ctypes.c_int32 * k)(*[int(f[0]) for f in factors])
+    basis = (ctypes.c_uint64 * k)()
+    ptrs = (ctypes.c_void_p * k)()
+    keep = []
+    for j, (n, x) in enumerate(factors):
+      if isinstance(x, (int, np.integer)):
+        basis[j] = int(x)
+      else:
+        a = np.ascontiguousarray(x, dtype=np.complex128).reshape(-1)
+        if a.size != 1 << n:
+          raise ValueError(f'factor {j}: {a.size} amplitudes for {n} qubits')
+        keep.append(a)
+        ptrs[j] = a.ctypes.data
+    native.check(self.lib.qh_init_product(self.h, k, nq, ptrs, basis))
 
   def upload(self, host, offset=0):
     a = np.ascontiguousarray(host, dtype=self.dtype)

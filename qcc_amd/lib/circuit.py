@@ -77,10 +77,15 @@ class qc:
         self.build_ir = not eager
         self.global_reg = 0
         self.sub_circuits = 0
-        # state bookkeeping: exactly one of (_basis, _host, _dev) is authoritative
+        # state bookkeeping: exactly one of (_factors, _host, _dev) is authoritative
         self._nbits = 0
-        self._basis = 0          # basis index while the state is still |basis>
-        self._is_basis = True    # True until something non-trivial happens
+        # while no gate has run the state is a tensor product of the pieces handed to
+        # reg()/qubit()/bitstring()/state(): [(nqubits, basis index | amplitudes)], most
+        # significant first.  It is built ON THE DEVICE (qh_init_product) when the first
+        # gate arrives -- the reference np.kron's on the host at every call
+        # (circuit.py:121-123).
+        self._factors = []
+        self._is_product = True  # True until something non-trivial happens
         self._host = None        # State snapshot (valid iff _host_ok)
         self._host_ok = False
         self._dev = None         # device state (valid iff _dev_ok)
@@ -114,8 +119,8 @@ class qc:
         if self._dev is None:
             self._dev = backend.make_device_state(self._nbits, self._width())
         if not self._dev_ok:
-            if self._is_basis:
-                self._dev.init_basis(self._basis)
+            if self._is_product:
+                self._dev.init_product(self._factors)
             else:
                 assert self._host_ok, 'no valid copy of the state'
                 self._dev.upload(np.asarray(self._host))
@@ -132,9 +137,15 @@ class qc:
                                   'qc.ampl(), qc.prob(), qc.measure_bit() (device-side readers) instead')
             if self._dev_ok:
                 host = state.State(self._dev.download())
-            else:  # still a basis state that never reached the device
-                vec = np.zeros(1 << self._nbits, dtype=tensor.tensor_type())
-                vec[self._basis] = 1
+            else:  # still a product state that never reached the device
+                vec = np.ones(1, dtype=tensor.tensor_type())
+                for n, x in self._factors:
+                    if isinstance(x, (int, np.integer)):
+                        t = np.zeros(1 << n, dtype=tensor.tensor_type())
+                        t[int(x)] = 1
+                    else:
+                        t = np.asarray(x, dtype=tensor.tensor_type())
+                    vec = np.kron(vec, t)
                 host = state.State(vec)
             host.flags.writeable = False
             self._host, self._host_ok = host, True
@@ -148,23 +159,27 @@ class qc:
         self._nbits = host.nbits if host.ndim else 0
         self._host, self._host_ok = host, True
         self._dev_ok = False
-        self._is_basis = False
+        self._is_product = False
+        self._factors = []
 
     def _tprod(self, new_state, nqubits):
         """psi <- psi (x) new_state (circuit.py:121-123)."""
-        idx = getattr(new_state, 'basis_index', None)
-        if self._is_basis and idx is not None:
-            self._tprod_basis(nqubits, idx)
+        if self._is_product:
+            idx = getattr(new_state, 'basis_index', None)
+            self._append_factor(nqubits, idx if idx is not None else np.array(new_state, dtype=np.complex128))
             return
         cur = self.psi if self._nbits else state.State(1.0)
         self.psi = cur * new_state
         self.global_reg += nqubits
 
-    def _tprod_basis(self, nqubits, index):
-        self._basis = (self._basis << nqubits) | index
+    def _append_factor(self, nqubits, what):
+        self._factors.append((int(nqubits), what))
         self._nbits += nqubits
         self.global_reg += nqubits
         self._host_ok = self._dev_ok = False
+
+    def _tprod_basis(self, nqubits, index):
+        self._append_factor(nqubits, int(index))
 
     class scope:
         """Context manager grouping gates into a named IR section."""
@@ -181,7 +196,7 @@ class qc:
     # ------------------------------------------------------------------ state builders
     def reg(self, size, it=0, *, name=None):
         ret = state.Reg(size, it, self.global_reg)
-        if self._is_basis:
+        if self._is_product:
             self._tprod_basis(size, helper.bits2val(ret.val))
         else:
             self._tprod(ret.psi(), size)
@@ -192,13 +207,13 @@ class qc:
         self._tprod(state.qubit(alpha, beta), 1)
 
     def zeros(self, n):
-        self._tprod(state.zeros(n), n) if not self._is_basis else self._tprod_basis(n, 0)
+        self._tprod(state.zeros(n), n) if not self._is_product else self._tprod_basis(n, 0)
 
     def ones(self, n):
-        self._tprod(state.ones(n), n) if not self._is_basis else self._tprod_basis(n, 2 ** n - 1)
+        self._tprod(state.ones(n), n) if not self._is_product else self._tprod_basis(n, 2 ** n - 1)
 
     def bitstring(self, *bits):
-        if self._is_basis:
+        if self._is_product:
             arr = np.asarray(bits)
             assert len(arr) and ((arr == 1) | (arr == 0)).all(), 'Bits must be 0 or 1'
             self._tprod_basis(len(bits), helper.bits2val(bits))
@@ -252,7 +267,7 @@ class qc:
                 assert idx < self._nbits, 'Invalid qubit index'
                 self._ensure_device().apply1(np.asarray(gate).reshape(4), idx)
                 self._host_ok = False
-                self._is_basis = False
+                self._is_product = False
 
     def applyc(self, gate, ctl, idx, name=None, *, val=None):
         """Apply `gate` on `idx` controlled by `ctl` ([ctl] = controlled by |0>)."""
@@ -267,7 +282,7 @@ class qc:
             assert idx < self._nbits, 'Invalid qubit index'
             self._ensure_device().applyc(np.asarray(gate).reshape(4), ctl_qubit, idx)
             self._host_ok = False
-            self._is_basis = False
+            self._is_product = False
         self.x(ctl_qubit, by_0)
 
     def cx0(self, idx0, idx1):
@@ -366,7 +381,7 @@ class qc:
             dev.project_bit(bit, 1 if tostate else 0)
             dev.scale(1.0 / math.sqrt(prob))
             self._host_ok = False
-            self._is_basis = False
+            self._is_product = False
         snapshot = self.psi if self._nbits <= 26 else None
         return prob, snapshot
 

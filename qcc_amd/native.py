@@ -49,6 +49,7 @@ SIGNATURES = {
     'qh_stream': (_i32, [_vp, ctypes.POINTER(_vp)]),
     'qh_nbits': (_i32, [_vp, ctypes.POINTER(_i32), ctypes.POINTER(_i32)]),
     'qh_init_basis': (_i32, [_vp, _u64]),
+    'qh_init_product': (_i32, [_vp, _i32, ctypes.POINTER(_i32), ctypes.POINTER(_vp), ctypes.POINTER(_u64)]),
     'qh_upload': (_i32, [_vp, _vp, _u64, _u64]),
     'qh_download': (_i32, [_vp, _vp, _u64, _u64]),
     'qh_apply1': (_i32, [_vp, _i32, _dp]),

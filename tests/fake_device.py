@@ -27,6 +27,17 @@ class OracleDevice:
     self.psi[:] = 0
     self.psi[index] = 1
 
+  def init_product(self, factors):
+    v = np.ones(1, dtype=np.complex128)
+    for n, x in factors:
+      if isinstance(x, (int, np.integer)):
+        t = np.zeros(1 << n, dtype=np.complex128)
+        t[int(x)] = 1
+      else:
+        t = np.asarray(x, dtype=np.complex128).reshape(-1)
+      v = np.kron(v, t)
+    self.psi[:] = v.astype(self.dtype)
+
   def upload(self, host, offset=0):
     host = np.asarray(host, dtype=self.dtype)
     self.psi[offset:offset + host.size] = host

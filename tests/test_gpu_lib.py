@@ -155,3 +155,22 @@ def test_large_register_never_touches_host():
   assert abs(qc.prob(*want0) - 0.5) < 1e-12
   assert qc._host is None
   qc.close()
+
+
+def test_product_registers_are_built_on_the_device():
+  """qc.qubit(alpha, beta) / qc.state() next to large registers: no host kron (N4)."""
+  from qcc_amd.lib import circuit, state
+  qc = circuit.qc('product')
+  qc.qubit(0.6, 0.8)
+  qc.reg(27, 3)
+  st = state.State(np.array([0.5, 0.5j, -0.5, 0.5]))
+  qc.state(st)
+  assert qc.nbits == 30 and qc._host is None
+  qc.h(29)                                   # first gate -> qh_init_product on the device
+  assert qc._host is None
+  s = 1 / np.sqrt(2)
+  # index = q<<29 | 3<<2 | k ;  H on the last qubit mixes k=0,1 and k=2,3
+  assert abs(qc.ampl(*([0] + [0] * 25 + [1, 1] + [0, 0])) - 0.6 * s * (0.5 + 0.5j)) < 1e-12
+  assert abs(qc.ampl(*([1] + [0] * 25 + [1, 1] + [1, 1])) - 0.8 * s * (-0.5 - 0.5)) < 1e-12
+  assert abs(qc.norm2() - 1.0) < 1e-12
+  qc.close()

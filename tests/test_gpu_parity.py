@@ -372,3 +372,36 @@ def test_unit_entry_butterflies_vs_oracle(oracle, bw):
           st.applyc(g, c, t)
       worst = max(worst, float(np.max(np.abs(st.download() - want))))
   assert worst <= (TOL if bw == 128 else 3e-6), worst
+
+
+@pytest.mark.parametrize('bw', [128, 64])
+def test_init_product_matches_kron(bw):
+  """qh_init_product == np.kron of the factors (circuit.py:121-164)."""
+  rng = np.random.default_rng(5)
+  dt = np.complex128 if bw == 128 else np.complex64
+
+  def rnd(n):
+    return _rand_state(rng, n)
+
+  factors = [(3, 5), (2, rnd(2)), (10, rnd(10)), (1, np.array([0.6, 0.8j])), (4, 9)]
+  want = np.ones(1, dtype=np.complex128)
+  for n, x in factors:
+    if isinstance(x, int):
+      t = np.zeros(1 << n, dtype=np.complex128)
+      t[x] = 1
+    else:
+      t = x
+    want = np.kron(want, t)
+  with device.DeviceState(20, bw, fusion=native.QH_FUSE_SWEEP) as st:
+    st.init_product(factors)
+    got = st.download()
+    assert got.dtype == dt
+    assert np.max(np.abs(got - want.astype(dt))) <= (1e-15 if bw == 128 else 1e-7)
+    assert abs(st.norm2() - 1.0) < 1e-6
+    # 33 single-qubit factors are merged on the host before they reach the C-ABI ...
+    many = [(1, np.array([0.6, 0.8]))] * 20
+    st.init_product(many)
+    assert abs(st.amplitude(0) - 0.6 ** 20) < (1e-12 if bw == 128 else 1e-7)
+    # ... and a factor list that does not add up is rejected
+    with pytest.raises(native.QhError):
+      st.init_product([(3, 1), (5, 2)])

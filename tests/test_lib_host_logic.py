@@ -87,10 +87,24 @@ def test_registers_stay_symbolic_until_needed():
   qc.bitstring(1, 0)
   qc.zeros(3); qc.ones(2)
   assert qc.nbits == 28 and qc._host is None and qc._dev is None   # nothing materialised
-  assert qc._basis == (((((5 << 1) | 1) << 2 | 0b10) << 3) << 2) | 0b11
+  from qcc_amd.device import merge_factors
+  assert merge_factors(qc._factors) == [(28, (((((5 << 1) | 1) << 2 | 0b10) << 3) << 2) | 0b11)]
+  # non-basis pieces stay factors too (built by qh_init_product on first use, never np.kron'ed)
+  qc.qubit(0.6, 0.8)
+  qc.reg(3, 1)
+  assert qc.nbits == 32 and qc._host is None and qc._dev is None
+  m = merge_factors(qc._factors)
+  assert [f[0] for f in m] == [28, 4] and np.allclose(m[1][1][[1, 9]], [0.6, 0.8])
   qc2 = circuit.qc('small')
   qc2.reg(3, 5)
   assert np.array_equal(np.asarray(qc2.psi), np.asarray(state.bitstring(1, 0, 1)))
+  qc3 = circuit.qc('mixed')
+  qc3.reg(2, 2)
+  qc3.qubit(0.6, 0.8)
+  qc3.h(0)                                     # first gate: product built by the (fake) device
+  want = state.bitstring(1, 0) * state.qubit(0.6, 0.8)
+  want.apply1(ops.Hadamard(), 0)
+  assert np.allclose(np.asarray(qc3.psi), np.asarray(want))
 
 
 def test_snapshot_semantics():
