@@ -174,3 +174,38 @@ def test_product_registers_are_built_on_the_device():
   assert abs(qc.ampl(*([1] + [0] * 25 + [1, 1] + [1, 1])) - 0.8 * s * (-0.5 - 0.5)) < 1e-12
   assert abs(qc.norm2() - 1.0) < 1e-12
   qc.close()
+
+
+def test_non_eager_circuit_runs_as_planned_sweeps():
+  """a recorded (non-eager) circuit reaches the planner whole at qc.run() /
+  qc.qc(sub) (ir.py, circuit.py:394-423) -- a 22-qubit QFT becomes a handful of sweeps."""
+  n, x = 22, 0x2B5C3
+  qc = circuit.qc('recorded', eager=False)
+  reg = qc.reg(n, tuple(int(b) for b in format(x, f'0{n}b')))
+  qc.qft(reg)
+  assert qc.ir.ngates == n * (n + 1) // 2 and qc._dev is None       # nothing executed yet
+  qc.run()
+  dev = qc._dev
+  dev.flush()
+  st = dev.stats()
+  assert st['gates_submitted'] == n * (n + 1) // 2 and st['kernels_launched'] <= 4 and st['sweeps'] == st['kernels_launched']
+  ks = (0, 1, 12345, (1 << n) - 1)
+  amps = workloads.qft_analytic(n, x, np.array(ks))
+  got = np.array([qc.ampl(*[int(b) for b in format(int(k), f'0{n}b')]) for k in ks])
+  assert np.max(np.abs(got - amps)) < 1e-12
+  # the adjoint of the recorded circuit, replayed into an eager circuit holding QFT|x>
+  main = circuit.qc('main')
+  main.reg(n, tuple(int(b) for b in format(x, f'0{n}b')))
+  main.qc(qc)
+  main.qc(qc.inverse())
+  bits, p = main.maxprob()
+  assert abs(p - 1.0) < 1e-10 and helper_bits(bits) == x
+  qc.close()
+  main.close()
+
+
+def helper_bits(bits):
+  v = 0
+  for b in bits:
+    v = (v << 1) | int(b)
+  return v
