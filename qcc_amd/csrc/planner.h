@@ -53,12 +53,13 @@ constexpr int kMaxRegBits = 5; // 32 amplitudes (128 VGPRs of data) per lane
 constexpr int kMaxSweepOps = 1024;
 constexpr int kMaxInsertBits = 12;  // == kMaxIns of kernels_gate.hip.h (tile enumeration)
 
-enum : uint32_t { OP_DENSE_REG = 0, OP_DENSE_LANE = 1, OP_DIAG = 2 };
+enum : uint32_t { OP_DENSE_REG = 0, OP_DENSE_LANE = 1, OP_DIAG = 2, OP_LSWAP = 3 };  // LSWAP: lane bit tb (4|5) <-> register bit 0
 // A DIAG op directly followed by an uncontrolled dense op on a LANE bit does not
 // apply its per-lane factor c to the 2^RB slots: the dense op folds it into its
 // per-lane matrix coefficients (H.diag(c)), two complex products per lane.
 enum : uint32_t { OPF_DEFER_C = 1, OPF_USE_C = 2, OPF_REAL = 4,  // REAL: all four entries real
-                  OPF_BFLY = 8, OPF_BFLY_SHIFT = 4 };              // unit-entry butterfly, variant in bits 4..6
+                  OPF_BFLY = 8, OPF_BFLY_SHIFT = 4,                // unit-entry butterfly, variant in bits 4..6
+                  OPF_LANE_DPP = 128, OPF_SWAP_RI = 256 };         // lane butterfly by DPP moves; partner re/im exchanged
 
 // Gates of the form c*M with every entry of M in {1,-1,i,-i} (h, yroot, v = sqrt-x and
 // their adjoints: ops.py:130-132,152-162) cost additions only once the scalar c is moved
@@ -217,9 +218,10 @@ class Planner {
   uint64_t amp_bytes_;
   int rb_cap_;
   bool split_lanes_;   // allow lane bits 3..5 to sit on arbitrary index bits (8 free tile bits)
-  bool butterflies_ = env_flag("QH_BFLY", true);
+  bool butterflies_ = env_flag("QH_BFLY", true);        // unit-entry butterfly ops (emit_ops_with)
   size_t dense_weight_ = env_int("QH_PLAN_DENSE_W", 1);  // score of a dense gate when choosing tile bits (diagonal = 1)
-  bool defer_diag_ = env_flag("QH_DEFER_DIAG", true);   // see build_sweep  // unit-entry butterfly ops (settle_butterflies)
+  int lane_valu_ = env_int("QH_LANE_VALU", 1);          // 0 never, 1 by cost model (choose_lane_paths), 2 always (tests)
+  bool defer_diag_ = env_flag("QH_DEFER_DIAG", true);   // see build_sweep
   std::vector<uint64_t> alg_override_;
   std::vector<uint32_t> weight_;  // reference gate applications each pending record stands for
 
@@ -533,10 +535,109 @@ class Planner {
 
   struct PTerm { uint64_t mask; double re, im; };
 
+  // How many lane butterflies leave the LDS (ds_bpermute) path, by lane-bit class.
+  struct LaneChoice { int dpp01 = 0, dpp23 = 0, lswap = 0; };
+
+  // ds_bpermute_b32 issues once per ~6.1 cycles per CU (tools/membench/bpermbench: the LDS
+  // pipe is shared by the four SIMDs), a VALU instruction once per ~1.18.  A sweep with many
+  // lane-bit gates is therefore bound by the LDS pipe long before HBM (supremacy: 21 lane
+  // ops -> 15 ms for a 6 ms sweep).  Lane butterflies can instead fetch the partner by DPP
+  // moves (lane bits 0..3) or exchange lane bit 4/5 with register bit 0 by
+  // v_permlane{16,32}_swap and run as register butterflies: more VALU work, no LDS.  The
+  // split is chosen per sweep so that neither pipe exceeds the other (cycles per tile per CU).
+  LaneChoice choose_lane_paths(const SweepPlan &sp) const {
+    const double kLds = 6.1 * (amp_bytes_ == 16 ? 128 : 64), kValu = 1.18;
+    const double dw = amp_bytes_ == 16 ? 1.0 : 0.5;
+    double lds = 0, valu = 0;
+    int n01 = 0, n23 = 0, n45 = 0;
+    for (const SweepOp &o : sp.ops) {
+      if (o.kind == OP_DIAG) {
+        bool c_part = false;
+        for (uint32_t gi = 0; gi < o.n_groups; ++gi) {
+          const DGroup &g = sp.groups[o.group_off + gi];
+          const int pc = popc(g.reg_mask);
+          valu += 24 + 12.0 * g.ntab + (pc == 0 ? 4 : (128 >> pc));
+          c_part |= pc == 0;
+        }
+        if (c_part && !(o.flags & OPF_DEFER_C)) valu += 128;
+        continue;
+      }
+      const bool lane = o.kind == OP_DENSE_LANE;
+      if (lane) lds += kLds;
+      if (o.flags & OPF_BFLY) {
+        valu += 64;
+        if (lane) (o.tb < 2 ? n01 : o.tb < 4 ? n23 : n45)++;
+      } else if (o.flags & OPF_REAL) valu += lane ? 128 : 160;
+      else valu += lane ? 384 : 400;
+    }
+    valu *= kValu;
+    LaneChoice ch;
+    const double floor_cycles = 5500;           // ~0.8 x the HBM time of a tile (6 ms sweep, 2048 tiles per CU)
+    auto take = [&](int *have, int *out, double add_instr) {
+      while (*have > 0 && lds > std::max(valu, floor_cycles) && valu + add_instr * kValu * dw < lds) {
+        lds -= kLds;
+        valu += add_instr * kValu * dw;
+        --*have;
+        ++*out;
+      }
+    };
+    take(&n01, &ch.dpp01, 128);                 // 4 DPP moves per slot
+    take(&n45, &ch.lswap, 256);                 // swap in + swap out, 64 double-rate instructions each
+    take(&n23, &ch.dpp23, 256);                 // 8 DPP moves per slot
+    return ch;
+  }
+
   // Diagonal gates are placed LAZILY: a phase term stays pending until a dense
   // op targets one of its bits (or the sweep ends), so the terms of many
   // reference gates meet in few DIAG ops and merge into tables.
   void emit_ops(const std::vector<const GateRec *> &taken, SweepPlan *sp) {
+    emit_ops_with(taken, sp, LaneChoice{});
+    if (!lane_valu_) return;
+    LaneChoice ch = choose_lane_paths(*sp);
+    if (lane_valu_ == 2) ch.dpp01 = ch.dpp23 = ch.lswap = 1 << 20;
+    if (ch.dpp01 + ch.dpp23 + ch.lswap == 0) return;
+    sp->ops.clear(); sp->groups.clear(); sp->oterms.clear(); sp->tables.clear();
+    emit_ops_with(taken, sp, ch);
+  }
+
+  void emit_ops_with(const std::vector<const GateRec *> &taken, SweepPlan *sp, LaneChoice ch) {
+    // Butterflies (unit-entry gates c*M, see butterfly_variant): the scalars c are multiplied
+    // into ONE uncontrolled dense gate of the sweep (a scalar commutes with everything) -- the
+    // last one, which runs on the general path.  Without such a sink nothing is converted.
+    std::vector<int8_t> role(taken.size(), 0);   // 1 = butterfly, 2 = sink
+    double pr = 1, pi = 0;
+    {
+      int sink = -1, nbf = 0;
+      std::vector<int> cand;
+      for (size_t i = 0; i < taken.size(); ++i) {
+        const GateRec *r = taken[i];
+        if (plan_diag(r->g, r->tgt) || (r->ctl_mask & ~sp->fixed_ones)) continue;
+        sink = (int)i;
+        if (butterflies_ && butterfly_variant(r->g) >= 0) cand.push_back((int)i);
+      }
+      for (int i : cand) if (i != sink) nbf++;
+      if (nbf >= 1) {
+        for (int i : cand) if (i != sink) { role[i] = 1; cmul_acc(&pr, &pi, taken[i]->g[0], taken[i]->g[1]); }
+        role[sink] = 2;
+      }
+    }
+    // current tile geometry: OP_LSWAP exchanges a lane bit with register bit 0 on the fly
+    SweepPlan geom;
+    geom.rb = sp->rb;
+    geom.fixed_ones = sp->fixed_ones;
+    memcpy(geom.regpos, sp->regpos, sizeof geom.regpos);
+    memcpy(geom.lanehi, sp->lanehi, sizeof geom.lanehi);
+    std::vector<int> swaps;                       // lane bits exchanged so far (undone in reverse)
+    auto lswap = [&](int li) {
+      SweepOp op{};
+      op.kind = OP_LSWAP;
+      op.tb = (uint32_t)li;
+      sp->ops.push_back(op);
+      std::swap(geom.lanehi[li - kLaneLow], geom.regpos[0]);
+    };
+    auto restore_layout = [&]() {
+      while (!swaps.empty()) { lswap(swaps.back()); swaps.pop_back(); }
+    };
     std::vector<PTerm> pending;
     auto add_pending = [&](uint64_t mask, double re, double im) {
       if (is_one(re, im)) return;
@@ -547,26 +648,59 @@ class Planner {
       }
       pending.push_back(PTerm{mask, re, im});
     };
-    for (const GateRec *r : taken) {
+    for (size_t gi = 0; gi < taken.size(); ++gi) {
+      const GateRec *r = taken[gi];
       const bool diag = plan_diag(r->g, r->tgt);
       if (!diag) {
         const size_t n_ops_before = sp->ops.size();
-        flush_diag(&pending, 1ull << r->tgt, sp);
+        flush_diag(&pending, 1ull << r->tgt, sp, geom);
         // non-zero only when THIS flush emitted a DIAG op right in front of the dense op
-        const size_t n_ops_after_flush = sp->ops.size() > n_ops_before ? sp->ops.size() : 0;
+        size_t n_ops_after_flush = sp->ops.size() > n_ops_before ? sp->ops.size() : 0;
         SweepOp op{};
         uint32_t lane, reg; uint64_t outside, lane_phys;
-        split_mask(*sp, r->ctl_mask, &lane, &lane_phys, &reg, &outside);
+        split_mask(geom, r->ctl_mask, &lane, &lane_phys, &reg, &outside);
+        if (lane && !swaps.empty()) {
+          // lane-bit controls are tested against the thread's ORIGINAL index bits
+          restore_layout();
+          n_ops_after_flush = 0;
+          split_mask(geom, r->ctl_mask, &lane, &lane_phys, &reg, &outside);
+        }
         op.cm_thread = outside | lane_phys;   // tested against the thread's physical index
         op.cm_reg = reg;
         memcpy(op.g, r->g, sizeof op.g);
-        const int li = lane_index(*sp, r->tgt);
+        if (role[gi] == 2) for (int k = 0; k < 4; ++k) cmul_acc(&op.g[2 * k], &op.g[2 * k + 1], pr, pi);
+        int li = lane_index(geom, r->tgt);
+        const int bv = role[gi] == 1 ? butterfly_variant(r->g) : -1;
+        if (bv >= 0 && li >= 4 && ch.lswap > 0) {   // lane bit 4/5 <-> register bit 0, then a register butterfly
+          ch.lswap--;
+          lswap(li);
+          swaps.push_back(li);
+          n_ops_after_flush = 0;
+          li = -1;
+        }
         if (li >= 0) { op.kind = OP_DENSE_LANE; op.tb = (uint32_t)li; }
-        else { op.kind = OP_DENSE_REG; op.tb = reg_index(*sp, r->tgt); }
-        if (r->g[1] == 0.0 && r->g[3] == 0.0 && r->g[5] == 0.0 && r->g[7] == 0.0) op.flags |= OPF_REAL;
-        const bool uncontrolled = op.cm_thread == 0 && op.cm_reg == 0;
-        const int bv = uncontrolled && butterflies_ ? butterfly_variant(r->g) : -1;
-        if (bv >= 0) op.flags |= OPF_BFLY | ((uint32_t)bv << OPF_BFLY_SHIFT);   // settled by settle_butterflies()
+        else { op.kind = OP_DENSE_REG; op.tb = reg_index(geom, r->tgt); }
+        if (op.g[1] == 0.0 && op.g[3] == 0.0 && op.g[5] == 0.0 && op.g[7] == 0.0) op.flags |= OPF_REAL;
+        if (bv >= 0) {
+          op.flags = OPF_BFLY | ((uint32_t)bv << OPF_BFLY_SHIFT);
+          memset(op.g, 0, sizeof op.g);
+          if (bv == 1) { op.g[0] = -1.0; op.g[1] = 1.0; }        // LDS lane form: new = own + beta*partner,
+          else if (bv == 2) { op.g[0] = 1.0; op.g[1] = -1.0; }   // beta on the 0-lane / on the 1-lane
+          int *budget = (li >= 0 && li < 2) ? &ch.dpp01 : (li >= 2 && li < 4) ? &ch.dpp23 : nullptr;
+          if (budget && *budget > 0) {
+            // DPP path: new.re = own.re + b_re*q.re, new.im = own.im + b_im*q.im with q the partner
+            // (re/im exchanged for v, v^+); g = b_re(0-lane), b_re(1-lane), b_im(0-lane), b_im(1-lane).
+            // h = [[1,1],[1,-1]] = Z * [[1,1],[-1,1]]: run variant 2, the Z joins the diagonal terms.
+            --*budget;
+            op.flags |= OPF_LANE_DPP;
+            static const double kBeta[5][4] = {{1, -1, 1, -1}, {-1, 1, -1, 1}, {1, -1, 1, -1}, {1, 1, -1, -1}, {-1, -1, 1, 1}};
+            memcpy(op.g, kBeta[bv], sizeof kBeta[bv]);
+            if (bv >= 3) op.flags |= OPF_SWAP_RI;
+            sp->ops.push_back(op);
+            if (bv == 0) add_pending(1ull << r->tgt, -1.0, 0.0);
+            continue;
+          }
+        }
         // (for a REAL gate folding would turn its 4-op real path into the 9-op complex
         // one: no gain over applying c to the slots, so only complex gates fold)
         if (!(op.flags & (OPF_REAL | OPF_BFLY)) && op.kind == OP_DENSE_LANE && op.cm_thread == 0 && op.cm_reg == 0 && !sp->ops.empty() &&
@@ -590,39 +724,8 @@ class Planner {
         add_pending(bits, (d1r * d0r + d1i * d0i) / den, (d1i * d0r - d1r * d0i) / den);
       }
     }
-    flush_diag(&pending, ~0ull, sp);
-    settle_butterflies(sp);
-  }
-
-  // The scalars c of the butterfly ops are multiplied into ONE uncontrolled dense op of
-  // the sweep (a scalar commutes with everything): the last one, which then runs on the
-  // general path.  Without such a sink nothing is converted.
-  static void settle_butterflies(SweepPlan *sp) {
-    int sink = -1, nbf = 0;
-    for (size_t i = 0; i < sp->ops.size(); ++i) {
-      const SweepOp &o = sp->ops[i];
-      if (o.kind == OP_DIAG || o.cm_thread != 0 || o.cm_reg != 0) continue;
-      sink = (int)i;
-      if (o.flags & OPF_BFLY) nbf++;
-    }
-    const bool sink_is_bf = sink >= 0 && (sp->ops[sink].flags & OPF_BFLY);
-    const bool convert = nbf - (sink_is_bf ? 1 : 0) >= 1;
-    double pr = 1, pi = 0;
-    for (size_t i = 0; i < sp->ops.size(); ++i) {
-      SweepOp &o = sp->ops[i];
-      if (!(o.flags & OPF_BFLY)) continue;
-      if (!convert || (int)i == sink) { o.flags &= ~(OPF_BFLY | (7u << OPF_BFLY_SHIFT)); continue; }
-      cmul_acc(&pr, &pi, o.g[0], o.g[1]);
-      const uint32_t v = (o.flags >> OPF_BFLY_SHIFT) & 7u;
-      memset(o.g, 0, sizeof o.g);
-      if (v == 1) { o.g[0] = -1.0; o.g[1] = 1.0; }        // lane form: new = own + beta*partner,
-      else if (v == 2) { o.g[0] = 1.0; o.g[1] = -1.0; }   // beta on the 0-lane / on the 1-lane
-    }
-    if (!convert) return;
-    SweepOp &o = sp->ops[sink];
-    for (int k = 0; k < 4; ++k) cmul_acc(&o.g[2 * k], &o.g[2 * k + 1], pr, pi);
-    if (o.g[1] == 0.0 && o.g[3] == 0.0 && o.g[5] == 0.0 && o.g[7] == 0.0) o.flags |= OPF_REAL;
-    else o.flags &= ~OPF_REAL;
+    flush_diag(&pending, ~0ull, sp, geom);
+    restore_layout();
   }
 
   static void cmul_acc(double *re, double *im, double fr, double fi) {
@@ -632,7 +735,7 @@ class Planner {
 
   // Emit one DIAG op with every pending term touching `bits` (all terms when
   // bits == ~0, including bit-less global factors).
-  void flush_diag(std::vector<PTerm> *pending, uint64_t bits, SweepPlan *sp) {
+  void flush_diag(std::vector<PTerm> *pending, uint64_t bits, SweepPlan *sp, const SweepPlan &geom) {
     std::vector<PTerm> sel, keep;
     for (auto &t : *pending) ((bits == ~0ull || (t.mask & bits)) ? sel : keep).push_back(t);
     pending->swap(keep);
@@ -645,7 +748,7 @@ class Planner {
     std::vector<PGroup> groups;
     for (auto &t : sel) {
       uint32_t lane, reg; uint64_t outside, lane_phys;
-      split_mask(*sp, t.mask, &lane, &lane_phys, &reg, &outside);
+      split_mask(geom, t.mask, &lane, &lane_phys, &reg, &outside);
       PGroup *g = nullptr;
       for (auto &pg : groups) if (pg.lane == lane && pg.reg == reg) { g = &pg; break; }
       if (!g) { groups.push_back(PGroup{lane, reg}); g = &groups.back(); }
@@ -745,16 +848,22 @@ inline std::string plan_to_json(const std::vector<GateRec> &queue, int nloc, uin
   for (size_t i = 0; i < pr.sweeps.size(); ++i) {
     const SweepPlan &sp = pr.sweeps[i];
     int nd = 0, ndiag = 0, nbf = 0;
-    for (auto &o : sp.ops) { (o.kind == OP_DIAG ? ndiag : nd)++; if (o.flags & OPF_BFLY) nbf++; }
+    int nswap = 0, ndpp = 0;
+    for (auto &o : sp.ops) {
+      if (o.kind == OP_LSWAP) { nswap++; continue; }
+      (o.kind == OP_DIAG ? ndiag : nd)++;
+      if (o.flags & OPF_BFLY) nbf++;
+      if (o.flags & OPF_LANE_DPP) ndpp++;
+    }
     std::string rp = "[";
     for (int k = 0; k < sp.rb; ++k) rp += (k ? "," : "") + std::to_string(sp.regpos[k]);
     rp += "],\"lanehi\":[";
     for (int k = 0; k < kLaneHi; ++k) rp += (k ? "," : "") + std::to_string(sp.lanehi[k]);
     rp += "]";
     snprintf(buf, sizeof buf,
-             "%s{\"gates\":%llu,\"dense_ops\":%d,\"butterfly_ops\":%d,\"diag_ops\":%d,\"groups\":%zu,\"oterms\":%zu,\"table_entries\":%zu,"
+             "%s{\"gates\":%llu,\"dense_ops\":%d,\"butterfly_ops\":%d,\"dpp_ops\":%d,\"lswap_ops\":%d,\"diag_ops\":%d,\"groups\":%zu,\"oterms\":%zu,\"table_entries\":%zu,"
              "\"regpos\":%s,\"fixed_ones\":%llu,\"ntiles\":%llu,\"alg_bytes\":%llu,\"swept_bytes\":%llu}",
-             i ? "," : "", (unsigned long long)sp.gates, nd, nbf, ndiag, sp.groups.size(), sp.oterms.size(),
+             i ? "," : "", (unsigned long long)sp.gates, nd, nbf, ndpp, nswap, ndiag, sp.groups.size(), sp.oterms.size(),
              sp.tables.size() / 2, rp.c_str(), (unsigned long long)sp.fixed_ones, (unsigned long long)sp.ntiles,
              (unsigned long long)sp.alg_bytes, (unsigned long long)sp.swept_bytes);
     s += buf;

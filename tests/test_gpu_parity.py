@@ -335,12 +335,16 @@ def test_complex64_qft_fused_analytic():
   assert np.max(np.abs(got - want)) < 2e-6 * 5
 
 
+@pytest.mark.parametrize('lane_valu', ['1', '2'])
 @pytest.mark.parametrize('bw', [128, 64])
-def test_unit_entry_butterflies_vs_oracle(oracle, bw):
+def test_unit_entry_butterflies_vs_oracle(oracle, bw, lane_valu, monkeypatch):
   """h / yroot / v and adjoints run as add-only butterflies inside a sweep (planner.h
   settle_butterflies, island L_bf*); their scalars land in one other gate.  Every
   variant on every bit of a 13-qubit state (lane bits, split-lane bits, register
-  bits), next to a general gate, and all-butterfly sweeps (the sink is a butterfly)."""
+  bits), next to a general gate, and all-butterfly sweeps (the sink is a butterfly).
+  lane_valu=2 forces the no-LDS lane paths (DPP partner fetch on lane bits 0..3,
+  v_permlane swaps for lane bits 4/5) that the planner otherwise picks by cost model."""
+  monkeypatch.setenv('QH_LANE_VALU', lane_valu)
   n = 13
   dt = np.complex128 if bw == 128 else np.complex64
   rng = np.random.default_rng(99)

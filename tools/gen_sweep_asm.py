@@ -176,6 +176,8 @@ def gen(rb, wide=True):
   a('s_waitcnt lgkmcnt(0)')
   a('s_cmp_eq_u32 s44, 2')
   a(f's_cbranch_scc1 {L("L_diag")}')
+  a('s_cmp_eq_u32 s44, 3')                    # OP_LSWAP: exchange lane bit 4/5 with register bit 0
+  a(f's_cbranch_scc1 {L("L_lswap")}')
   a('s_bitcmp1_b32 s51, 3')                   # OPF_BFLY: uncontrolled unit-entry butterfly
   a(f's_cbranch_scc1 {L("L_bf")}')
   # control predicate of this thread: (it & cm_thread) == cm_thread  -> s[68:69]
@@ -286,6 +288,27 @@ def gen(rb, wide=True):
         a(MOV() + f' {X(k0)}, {ta}')
         a(MOV() + f' {Y(k0)}, {tb}')
     a(f's_branch {L("L_next")}')
+  def lane_pipeline(first_buf, depth, combine_slot):
+    """Partner values of slot k arrive by ds_bpermute `depth` slots ahead of their use
+    (the shuffle latency, not its issue rate, bounds a lane op: SQ_WAIT_INST_LDS was 42%
+    of the wave time with one slot of lookahead)."""
+    bufs = [first_buf + 2 * W() * j for j in range(depth)]
+    assert bufs[-1] + 2 * W() - 1 <= TEMP_HI and (depth - 1) * 2 * W() <= 15
+
+    def shuf_to(k, buf):
+      for d in range(2 * W()):
+        a(f'ds_bpermute_b32 v{buf + d}, v{LN_ADDR}, v{T(k) + d}')
+
+    for k in range(min(depth, nr)):
+      shuf_to(k, bufs[k % depth])
+    for k in range(nr):
+      ahead = min(k + depth - 1, nr - 1) - k
+      a(f's_waitcnt lgkmcnt({ahead * 2 * W()})')
+      buf = bufs[k % depth]
+      combine_slot(k, V2(buf), V2(buf + W()))
+      if k + depth < nr:
+        shuf_to(k + depth, buf)
+
   # lane bit, real: new = ca*mine + cb*other with real per-lane ca, cb -- 4 FP64 ops per slot
   a.label('L_lane_real')
   a('s_lshl_b32 s74, 1, s45')
@@ -311,20 +334,13 @@ def gen(rb, wide=True):
     for d in range(2 * W()):
       a(f'ds_bpermute_b32 v{buf + d}, v{LN_ADDR}, v{T(k) + d}')
 
-  shuf_r(0, LN_BUF[0])
-  for k in range(nr):
-    if k + 1 < nr:
-      shuf_r(k + 1, LN_BUF[(k + 1) & 1])
-      a(f's_waitcnt lgkmcnt({2 * W()})')
-    else:
-      a('s_waitcnt lgkmcnt(0)')
-    buf = LN_BUF[k & 1]
+  def comb_real(k, pr, pi):
     a(MUL() + f' {X(k)}, {rca}, {X(k)}')
     a(MUL() + f' {Y(k)}, {rca}, {Y(k)}')
-    a(FMA() + f' {X(k)}, {rcb}, {V2(buf)}, {X(k)}')
-    a(FMA() + f' {Y(k)}, {rcb}, {V2(buf + W())}, {Y(k)}')
+    a(FMA() + f' {X(k)}, {rcb}, {pr}, {X(k)}')
+    a(FMA() + f' {Y(k)}, {rcb}, {pi}, {Y(k)}')
+  lane_pipeline(24, 4, comb_real)
   a(f's_branch {L("L_next")}')
-
 
   # ---- unit-entry butterflies (OPF_BFLY): the gate is c*M with M's entries in {1,-1,i,-i};
   # the planner moved c into another op of the sweep, so M costs adds only, in place.
@@ -391,6 +407,8 @@ def gen(rb, wide=True):
       a(f's_branch {L("L_next")}')
   # lane bit: partner p via ds_bpermute, own value o
   a.label('L_bfl')
+  a('s_bitcmp1_b32 s51, 7')                   # OPF_LANE_DPP: partner values by DPP moves (VALU), not LDS
+  a(f's_cbranch_scc1 {L("L_dpp")}')
   a('s_lshl_b32 s75, 1, s45')
   a(f'v_xor_b32 v{LN_ADDR}, s75, %5')
   a(f'v_lshlrev_b32 v{LN_ADDR}, 2, v{LN_ADDR}')
@@ -403,14 +421,7 @@ def gen(rb, wide=True):
   a(f's_branch {L("L_next")}')
 
   def bf_lane(form):
-    shuf_r(0, LN_BUF[0])
-    for k in range(nr):
-      if k + 1 < nr:
-        shuf_r(k + 1, LN_BUF[(k + 1) & 1])
-        a(f's_waitcnt lgkmcnt({2 * W()})')
-      else:
-        a('s_waitcnt lgkmcnt(0)')
-      pr, pi = V2(LN_BUF[k & 1]), V2(LN_BUF[k & 1] + W())
+    def comb(k, pr, pi):
       if form == 'a':      # new = alpha*o + p
         a(FMA() + f' {X(k)}, {coef}, {X(k)}, {pr}')
         a(FMA() + f' {Y(k)}, {coef}, {Y(k)}, {pi}')
@@ -423,6 +434,7 @@ def gen(rb, wide=True):
       else:                # new = o + i p
         a(ADDS(X(k), X(k), pi, neg=True))
         a(ADDS(Y(k), Y(k), pr))
+    lane_pipeline(20, 4, comb)
     a(f's_branch {L("L_next")}')
 
   c0 = LN_COEF['car']
@@ -451,6 +463,79 @@ def gen(rb, wide=True):
   bf_lane('v')
   a.label('L_bfl_w')
   bf_lane('w')
+
+
+  # ---- OP_LSWAP: lane bit tb (4 or 5) <-> register bit 0, in place -----------------------
+  # v_permlane{16,32}_swap exchanges the odd rows / upper half of one register with the even
+  # rows / lower half of another: applied to slots (k, k^1) it moves the pair a lane-bit gate
+  # acts on into ONE lane (registers k and k^1), i.e. afterwards that index bit is register
+  # bit 0 and the old register bit 0 is the lane bit.  The planner emits the gate as a
+  # register op in between and swaps back (the op is an involution).  No LDS traffic:
+  # ds_bpermute issues once per ~6 cycles per CU, these run at VALU rate.
+  a.label('L_lswap')
+  a('s_cmp_eq_u32 s45, 5')
+  a(f's_cbranch_scc1 {L("L_lswap32")}')
+  for name, ins in (('L_lswap16', 'v_permlane16_swap_b32'), ('L_lswap32', 'v_permlane32_swap_b32')):
+    a.label(name)
+    for k in range(0, nr, 2):
+      for d in range(2 * W()):
+        a(f'{ins} v{T(k) + d}, v{T(k + 1) + d}')
+    a(f's_branch {L("L_next")}')
+
+  # ---- butterfly on lane bit 0..3 with DPP partner fetch (OPF_LANE_DPP) -------------------
+  # new.re = o.re + beta_re * q.re ; new.im = o.im + beta_im * q.im, q = partner value, or the
+  # partner with re/im exchanged (flags bit 8; v / v^+).  beta = +-1 per lane: g[0..3] =
+  # beta_re(0-lane), beta_re(1-lane), beta_im(0-lane), beta_im(1-lane).
+  a.label('L_dpp')
+  a('s_lshl_b32 s75, 1, s45')
+  a(f'v_and_b32 v{LN_TMP}, s75, %5')
+  a(f'v_cmp_ne_u32 vcc, 0, v{LN_TMP}')
+  BRE, BIM, Q, TQ = 18, 18 + 2 * W(), 24, 28
+  if DT.wide:
+    for v, (lo, hi) in ((BRE, (52, 54)), (BIM, (56, 58))):
+      for d in range(2):
+        a(f'v_mov_b32 v{v + d}, s{lo + d}')
+        a(f'v_mov_b32 v{LN_TMP}, s{hi + d}')
+        a(f'v_cndmask_b32 v{v + d}, v{v + d}, v{LN_TMP}, vcc')
+  else:
+    for v, (lo, hi) in ((BRE, (52, 54)), (BIM, (56, 58))):
+      a(f'v_cvt_f32_f64 v{v}, s[{lo}:{lo + 1}]')
+      a(f'v_cvt_f32_f64 v{LN_TMP}, s[{hi}:{hi + 1}]')
+      a(f'v_cndmask_b32 v{v}, v{v}, v{LN_TMP}, vcc')
+  bre, bim = V2(BRE), V2(BIM)
+  a('s_bfe_u32 s75, s51, 0x10008')              # 1: partner's re/im exchanged
+  a('s_lshl_b32 s75, s75, 2')
+  a('s_add_u32 s75, s75, s45')                  # 4*exchanged + tb
+  for code in range(8):
+    a(f's_cmp_eq_u32 s75, {code}')
+    a(f's_cbranch_scc1 {L(f"L_dpp{code}")}')
+  a(f's_branch {L("L_next")}')
+  DPP1 = {0: ['quad_perm:[1,0,3,2]'], 1: ['quad_perm:[2,3,0,1]'],
+          2: ['row_half_mirror', 'quad_perm:[3,2,1,0]'], 3: ['row_mirror', 'row_half_mirror']}
+  for code in range(8):
+    tbv, exch = code & 3, code >> 2
+    a.label(f'L_dpp{code}')
+    a('s_nop 1')
+    steps = DPP1[tbv]
+    for k in range(nr):
+      nd = 2 * W()
+      # source dwords: q.re from the partner's re (or im when exchanged), q.im likewise
+      src = [T(k) + d for d in range(nd)]
+      if exch:
+        src = src[W():] + src[:W()]
+      if len(steps) == 1:
+        for d in range(nd):
+          a(f'v_mov_b32_dpp v{Q + d}, v{src[d]} {steps[0]} row_mask:0xf bank_mask:0xf')
+      else:
+        for d in range(nd):
+          a(f'v_mov_b32_dpp v{TQ + d}, v{src[d]} {steps[0]} row_mask:0xf bank_mask:0xf')
+        if nd < 3:
+          a('s_nop 1')
+        for d in range(nd):
+          a(f'v_mov_b32_dpp v{Q + d}, v{TQ + d} {steps[1]} row_mask:0xf bank_mask:0xf')
+      a(FMA() + f' {X(k)}, {bre}, {V2(Q)}, {X(k)}')
+      a(FMA() + f' {Y(k)}, {bim}, {V2(Q + W())}, {Y(k)}')
+    a(f's_branch {L("L_next")}')
 
   # ---- dense 2x2 on a lane bit: partner via ds_bpermute -------------------------------
   a.label('L_lane')

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Runs one named workload fused, `reps` times (for rocprofv3 traces): qft30 | sup30 | grover34 | qft30c64."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from qcc_amd import device, native, workloads  # noqa: E402
+
+name = sys.argv[1] if len(sys.argv) > 1 else 'sup30'
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+bw = 128
+if name == 'sup30':
+  n, init = 30, 0
+  ops, g8 = workloads.supremacy_stream(30, 20, seed=0).arrays()
+elif name == 'grover34':
+  n, init = 34, workloads.grover_initial_index(17)
+  ops, g8 = workloads.grover_stream(17, [1, 0] * 8 + [1], iterations=1).arrays()
+elif name == 'qft30c64':
+  n, init, bw = 30, 5, 64
+  ops, g8 = workloads.qft_stream(range(30)).arrays()
+else:
+  n, init = 30, 5
+  ops, g8 = workloads.qft_stream(range(30)).arrays()
+with device.DeviceState(n, bw, fusion=native.QH_FUSE_SWEEP) as st:
+  st.init_basis(init)
+  for _ in range(reps + 1):
+    st.run_stream(ops, g8)
+    st.flush()
+  st.sync()
+  print(st.stats())
