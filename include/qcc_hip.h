@@ -120,7 +120,7 @@ int qh_sync(qh_handle h);
 
 /* ---- logical -> physical bit map (global<->local qubit swaps) ----------- */
 /* Records that the DATA of physical bits a and b has been exchanged (by the
- * communication layer for a>=nbits_local, or by qh_swap_local_bits).  Later
+ * communication layer for a >= nbits_local).  Later
  * gates are routed through the map; readers report physical indices, convert
  * with qh_phys_to_logical.                                                   */
 int qh_remap_swap(qh_handle h, int phys_bit_a, int phys_bit_b);

@@ -187,19 +187,24 @@ def gen(rb, wide=True):
   a(f'v_cmp_eq_u32_e64 s[72:73], s49, v{V_B}')
   a('s_nop 1')
   a('s_and_b64 s[68:69], vcc, s[72:73]')
-  # REAL fast paths: all four matrix entries real (h, x, ry, cx ...) and no control at all
-  a('s_or_b32 s74, s48, s49')
-  a('s_or_b32 s74, s74, s46')
+  # REAL fast paths: all four matrix entries real (x, ry, cx, ccx ...) and no REGISTER-bit
+  # control.  Lane / outside-bit controls just narrow EXEC: the real paths update in place,
+  # so disabled lanes keep their amplitudes (a gate pair always shares its predicate).
   a('s_andn2_b32 s73, 4, s51')                # 0 iff OPF_REAL set
-  a('s_or_b32 s74, s74, s73')
+  a('s_or_b32 s74, s46, s73')
   a('s_cmp_eq_u32 s74, 0')
-  a(f's_cbranch_scc1 {L("L_real")}')
+  a(f's_cbranch_scc0 {L("L_generic")}')
+  a('s_and_b64 exec, exec, s[68:69]')
+  a(f's_cbranch_execz {L("L_next")}')
+  a(f's_branch {L("L_real")}')
+  a.label('L_generic')
   a('s_cmp_eq_u32 s44, 1')
   a(f's_cbranch_scc1 {L("L_lane")}')
   for b in range(rb):
     a(f's_cmp_eq_u32 s45, {b}')
     a(f's_cbranch_scc1 {L(f"L_reg{b}")}')
   a.label('L_next')
+  a('s_mov_b64 exec, -1')                     # (waves are always full: 64 x k threads per block)
   a('s_add_u32 s36, s36, 96')
   a('s_addc_u32 s37, s37, 0')
   a('s_sub_u32 s42, s42, 1')
