@@ -38,7 +38,7 @@ def parse():
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--sharded', action='store_true', help='use the multi-GPU layer even with one rank (smoke)')
   ap.add_argument('--cpu-qubits', type=int, default=30)
-  ap.add_argument('--cpu-gates', type=int, default=8, help='gates of the stream timed on the CPU')
+  ap.add_argument('--cpu-gates', type=int, default=14, help='gates of the stream timed on the CPU')
   return ap.parse_args()
 
 
