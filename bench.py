@@ -140,6 +140,8 @@ def main():
   from qcc_amd import device, native, workloads
   if native.device_count() < 1:
     raise SystemExit('bench.py: no HIP device visible; the engine has no CPU fallback')
+  if os.environ.get('QCC_DIST_BACKEND') == 'gloo':   # test mode: several ranks share the visible GPU(s)
+    local_rank %= native.device_count()
   gbits = int(math.log2(world))
   assert 1 << gbits == world, 'number of GPUs must be a power of two'
   n = args.qubits or (30 + gbits)
@@ -165,6 +167,8 @@ def main():
   eng.sync()
   eng.reset_stats()
   if dist is not None:
+    import torch
+    torch.cuda.synchronize()
     dist.barrier()
   t0 = time.perf_counter()
   eng.timer_begin()
@@ -174,11 +178,13 @@ def main():
   ev_ms = eng.timer_end()  # flushes + waits for the stream
   eng.sync()
   if dist is not None:
+    import torch
+    torch.cuda.synchronize()
     dist.barrier()
   wall = time.perf_counter() - t0
   if dist is not None:
     import torch
-    t = torch.tensor([wall], dtype=torch.float64, device='cuda')
+    t = torch.tensor([wall], dtype=torch.float64, device=eng._red_device())
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall = float(t.item())
   stats = eng.stats()
@@ -235,6 +241,9 @@ def main():
     if dist is not None:
       out['exchanges_per_step'] = stats.get('exchanges', 0) / steps
       out['xgmi_bytes_per_rank_per_step'] = stats.get('exchanged_bytes', 0) / steps
+      out['exchange_ms_per_step_rank0'] = stats.get('exchange_seconds', 0.0) / steps * 1e3
+      if stats.get('exchange_seconds', 0.0) > 0:
+        out['xgmi_GBps_per_rank'] = stats.get('exchanged_bytes', 0) / stats['exchange_seconds'] / 1e9
     if not args.no_cpu_baseline and world == 1:
       out['cpu_baseline'] = cpu_baseline(args, ops, g8)
       out['gpu_over_cpu'] = out['whole_state_gate_applies_per_s'] / out['cpu_baseline']['value']

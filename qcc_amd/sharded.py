@@ -62,7 +62,8 @@ class ShardedState:
     import torch.distributed as dist
     self.torch, self.dist = torch, dist
     if not dist.is_initialized():
-      backend = backend or ('nccl' if torch.cuda.is_available() else 'gloo')
+      # QCC_DIST_BACKEND=gloo: several ranks on ONE GPU (tests of this layer); RCCL refuses that
+      backend = backend or os.environ.get('QCC_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
       os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
       kw = {}
       if backend == 'nccl' and local_rank is not None:
@@ -92,6 +93,7 @@ class ShardedState:
     self._staging = None
     self.exchanges = 0
     self.exchanged_bytes = 0
+    self.exchange_seconds = 0.0
     self.gates = 0
 
   # ------------------------------------------------------------------ helpers
@@ -263,10 +265,14 @@ class ShardedState:
       self._finish_swap(prev)
 
   def _exchange(self, shard_phys_bit, base=None):
+    import time
+    self.eng.sync()                      # local kernels first: the timer below is the exchange alone
+    t0 = time.perf_counter()
     if self.exchange_mode == 'alltoall':
       self._exchange_all(base)
     else:
       self._exchange_pair(shard_phys_bit)
+    self.exchange_seconds += time.perf_counter() - t0
 
   def _evict_group(self, tbits, diag, k):
     """Which g consecutive local bits to hand to the shard index when gate k of a
@@ -435,12 +441,14 @@ class ShardedState:
     s = self.eng.stats()
     s['exchanges'] = self.exchanges
     s['exchanged_bytes'] = self.exchanged_bytes
+    s['exchange_seconds'] = self.exchange_seconds
     return s
 
   def reset_stats(self):
     self.eng.reset_stats()
     self.exchanges = 0
     self.exchanged_bytes = 0
+    self.exchange_seconds = 0.0
 
   def close(self):
     self.eng.sync()
