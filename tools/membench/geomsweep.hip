@@ -10,7 +10,7 @@
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 
 typedef double v2d __attribute__((ext_vector_type(2)));
-struct Geom { int pos[8]; int sorted[8]; int rot; int nblk_bits; };
+struct Geom { int pos[8]; int sorted[8]; int rot; int nblk_bits; int xs, xd, xw; };
 
 __global__ __launch_bounds__(256) void k_geom(v2d *__restrict__ p, uint64_t ntiles, Geom g) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -37,7 +37,9 @@ __global__ __launch_bounds__(256) void k_geom(v2d *__restrict__ p, uint64_t ntil
     uint64_t o = 0;
 #pragma unroll
     for (int b = 0; b < 5; ++b) o |= (uint64_t)((k >> b) & 1) << g.pos[3 + b];
-    a[k] = __builtin_nontemporal_load(&p[(j | o) + loff]);
+    uint64_t ix = (j | o) + loff;
+    if (g.xw) ix ^= ((ix >> g.xs) & ((1ull << g.xw) - 1)) << g.xd;
+    a[k] = __builtin_nontemporal_load(&p[ix]);
   }
 #pragma unroll
   for (int k = 0; k < 32; ++k) {
@@ -45,7 +47,9 @@ __global__ __launch_bounds__(256) void k_geom(v2d *__restrict__ p, uint64_t ntil
 #pragma unroll
     for (int b = 0; b < 5; ++b) o |= (uint64_t)((k >> b) & 1) << g.pos[3 + b];
     v2d t; t.x = a[k].x * 0.6 - a[k].y * 0.8; t.y = a[k].x * 0.8 + a[k].y * 0.6;
-    __builtin_nontemporal_store(t, &p[(j | o) + loff]);
+    uint64_t ix = (j | o) + loff;
+    if (g.xw) ix ^= ((ix >> g.xs) & ((1ull << g.xw) - 1)) << g.xd;
+    __builtin_nontemporal_store(t, &p[ix]);
   }
 }
 
@@ -60,7 +64,9 @@ int main(int argc, char **argv) {
     char buf[256]; strncpy(buf, argv[a], 255); buf[255] = 0;
     for (char *t = strtok(buf, ","); t && k < 8; t = strtok(nullptr, ",")) g.pos[k++] = atoi(t);
     g.rot = 0; g.nblk_bits = nb - 13;
+    g.xs = g.xd = g.xw = 0;
     if (k == 8) { char *c = strchr(argv[a], ':'); if (c) g.rot = atoi(c + 1); }
+    { char *c = strchr(argv[a], '^'); if (c) sscanf(c + 1, "%d,%d,%d", &g.xs, &g.xd, &g.xw); }
     if (k != 8) { printf("bad geometry %s\n", argv[a]); continue; }
     memcpy(g.sorted, g.pos, sizeof(g.pos)); std::sort(g.sorted, g.sorted + 8);
     float best = 1e9f;
