@@ -50,10 +50,13 @@ constexpr int kLaneLow = 3;    // lane bits 0..2 are ALWAYS index bits 0..2 (one
 constexpr int kLaneHi = 3;     // lane bits 3..5 sit on index bits 3,4,5 -- or on any three bits <= kMaxLaneHiBit
 constexpr int kMaxLaneHiBit = 27;  // per-lane byte offset must fit the 32-bit voffset of global_load
 constexpr int kMaxRegBits = 5; // 32 amplitudes (128 VGPRs of data) per lane
+constexpr int kMaxWaveBits = 2; // index bits selected by the wave id inside a workgroup ("super-tile", see OP_WSWAP)
 constexpr int kMaxSweepOps = 1024;
 constexpr int kMaxInsertBits = 12;  // == kMaxIns of kernels_gate.hip.h (tile enumeration)
 
-enum : uint32_t { OP_DENSE_REG = 0, OP_DENSE_LANE = 1, OP_DIAG = 2, OP_LSWAP = 3 };  // LSWAP: lane bit tb (4|5) <-> register bit 0
+enum : uint32_t { OP_DENSE_REG = 0, OP_DENSE_LANE = 1, OP_DIAG = 2,
+                  OP_LSWAP = 3,    // lane bit tb (4|5) <-> register bit 0 (v_permlane swaps)
+                  OP_WSWAP = 4 };  // wave bit tb <-> register bit 0 (through LDS); cm_thread = index bits that flip
 // A DIAG op directly followed by an uncontrolled dense op on a LANE bit does not
 // apply its per-lane factor c to the 2^RB slots: the dense op folds it into its
 // per-lane matrix coefficients (H.diag(c)), two complex products per lane.
@@ -101,6 +104,7 @@ struct OTerm {
 //   product of the single-bit outside factors of 8 consecutive index bits;
 //   lane table: 64 entries, product of all merged pure-lane factors.
 constexpr uint32_t DG_LTAB = 1u;
+constexpr uint32_t DG_LTAB_LDS = 2u;   // set at launch: this sweep's lane tables were copied into LDS
 struct DGroup {
   uint32_t lane_mask, reg_mask;
   uint32_t oterm_off, n_oterms;
@@ -124,12 +128,16 @@ struct SweepPlan {
   int rb = 0;                      // register bits used by the kernel instance
   int regpos[kMaxRegBits] = {0};   // ascending physical positions
   int lanehi[kLaneHi] = {3, 4, 5}; // ascending positions of lane bits 3,4,5 ({3,4,5} = contiguous 1-KiB runs)
+  int nwave = 0;                   // wave bits: the 2^nwave waves of a workgroup hold the tiles differing in
+  int wavepos[kMaxWaveBits] = {0}; // these index bits; a gate on one runs after OP_WSWAP moved it into registers
   uint64_t fixed_ones = 0;         // local bits fixed to 1 in the tile enumeration
   uint64_t ntiles = 0;             // wavefront tiles to process
   std::vector<SweepOp> ops;
   std::vector<DGroup> groups;
   std::vector<OTerm> oterms;
-  std::vector<double> tables;      // (re,im) pairs: lane tables and chunk tables
+  std::vector<double> tables;      // (re,im) pairs: lane tables FIRST (n_ltab x 64 entries), then chunk tables
+  std::vector<double> ltabs;       // lane tables while the sweep is being emitted (moved to the front of `tables`)
+  int n_ltab = 0;
   // accounting
   uint64_t gates = 0;              // reference gate applications executed by this sweep
   uint64_t alg_bytes = 0;          // their minimal-touch bytes
@@ -220,6 +228,8 @@ class Planner {
   bool split_lanes_;   // allow lane bits 3..5 to sit on arbitrary index bits (8 free tile bits)
   bool butterflies_ = env_flag("QH_BFLY", true);        // unit-entry butterfly ops (emit_ops_with)
   size_t dense_weight_ = env_int("QH_PLAN_DENSE_W", 1);  // score of a dense gate when choosing tile bits (diagonal = 1)
+  int max_wave_ = std::max(0, std::min(kMaxWaveBits, env_int("QH_WAVE_BITS", kMaxWaveBits)));
+  int min_table_terms_ = env_int("QH_MIN_TABLE_TERMS", 2);
   int lane_valu_ = env_int("QH_LANE_VALU", 1);          // 0 never, 1 by cost model (choose_lane_paths), 2 always (tests)
   bool defer_diag_ = env_flag("QH_DEFER_DIAG", true);   // see build_sweep
   std::vector<uint64_t> alg_override_;
@@ -347,16 +357,32 @@ class Planner {
   // tools/membench/splitlane.hip) but the sweep can then take EIGHT new target bits
   // instead of five.  Split a chosen bit set into (lane-high, register) bits; false
   // if it does not fit.
-  bool assign_bits(const std::vector<int> &sel, std::vector<int> *lanehi, std::vector<int> *regs) const {
+  // With wave bits the tile grows by up to two more bits (the HIGHEST chosen ones: a wave
+  // bit costs nothing in the memory access pattern of a wave).  Order of preference for the
+  // bits above bit 5: registers, wave bits, split lanes.
+  bool assign_bits(const std::vector<int> &sel, std::vector<int> *lanehi, std::vector<int> *regs,
+                   std::vector<int> *waves) const {
     std::vector<int> low, other;
     for (int b : sel) ((b >= kLaneLow && b < kLaneBits) ? low : other).push_back(b);
     std::sort(low.begin(), low.end());
     std::sort(other.begin(), other.end());
-    const int need_move = std::max<int>(0, (int)other.size() - rb_cap_);
+    const int extra = std::max<int>(0, (int)other.size() - rb_cap_);
+    const int nw = std::min(extra, max_wave_);
+    const int need_move = extra - nw;
     if (need_move > 0 && !split_lanes_) return false;
     if ((int)low.size() + need_move > kLaneHi) return false;
+    if (need_move > 0) {
+      // split-lane tile: the LOWEST bits go to the wave id, the highest to the registers
+      // (tools/geom_scan_waves.py, targets 13..22: 7.9 ms vs 8.8 ms the other way round)
+      waves->assign(other.begin(), other.begin() + nw);
+      other.erase(other.begin(), other.begin() + nw);
+    } else {
+      // contiguous lanes: highest bits to the wave id (tools/geom_scan_waves7.py)
+      waves->assign(other.end() - nw, other.end());
+      other.resize(other.size() - nw);
+    }
     for (int k = 0; k < need_move; ++k)
-      if (other[k] > kMaxLaneHiBit) return false;
+      if (other[k] > kMaxLaneHiBit) return false;   // lane offsets are 32-bit byte offsets
     *lanehi = low;
     lanehi->insert(lanehi->end(), other.begin(), other.begin() + need_move);
     regs->assign(other.begin() + need_move, other.end());
@@ -390,16 +416,16 @@ class Planner {
           std::find(cand.begin(), cand.end(), r.tgt) == cand.end())
         cand.push_back(r.tgt);
     }
-    std::vector<int> sel, lanehi, regs;
+    std::vector<int> sel, lanehi, regs, waves;
     size_t best_total = pass(pending, always, window, nullptr);
-    while ((int)sel.size() < kLaneHi + rb_cap_) {
+    while ((int)sel.size() < kLaneHi + rb_cap_ + max_wave_) {
       int best_bit = -1;
       size_t best = best_total;
       for (int c : cand) {
         if (std::find(sel.begin(), sel.end(), c) != sel.end()) continue;
-        std::vector<int> trial = sel, l, r;
+        std::vector<int> trial = sel, l, r, wv;
         trial.push_back(c);
-        if (!assign_bits(trial, &l, &r)) continue;
+        if (!assign_bits(trial, &l, &r, &wv)) continue;
         const size_t sc = pass(pending, always | mask_of(trial), window, nullptr);
         if (sc > best) { best = sc; best_bit = c; }
       }
@@ -407,11 +433,11 @@ class Planner {
       sel.push_back(best_bit);
       best_total = best;
     }
-    assign_bits(sel, &lanehi, &regs);
+    assign_bits(sel, &lanehi, &regs, &waves);
     uint64_t regmask = mask_of(regs);
     const uint64_t lanemask = always | mask_of(lanehi);
     std::vector<uint8_t> flags(pending.size(), 0);
-    pass(pending, lanemask | regmask, pending.size(), &flags);
+    pass(pending, lanemask | regmask | mask_of(waves), pending.size(), &flags);
     // A diagonal gate that no dense op of THIS sweep waits for, but a dense gate of a later
     // sweep does, is left for that sweep: there its factor joins the group that is applied
     // in front of that dense op anyway (one more table factor), instead of costing a group
@@ -449,6 +475,7 @@ class Planner {
       rest_w->erase(rest_w->begin());
       if (!plan_diag(pending[0].g, pending[0].tgt) && !((lanemask >> pending[0].tgt) & 1ull)) {
         regs.assign(1, pending[0].tgt);
+        waves.clear();
         regmask = 1ull << pending[0].tgt;
       }
       sp.gates = weight_[0];
@@ -462,7 +489,15 @@ class Planner {
       std::vector<int> keep;
       for (int p : regs) if ((used >> p) & 1ull) keep.push_back(p);
       regs.swap(keep);
+      keep.clear();
+      for (int p : waves) if ((used >> p) & 1ull) keep.push_back(p);
+      waves.swap(keep);
+      if (regs.empty() && !waves.empty()) {   // OP_WSWAP needs a register bit to exchange with
+        regs.push_back(waves.back());
+        waves.pop_back();
+      }
     }
+    const uint64_t wavemask = mask_of(waves);
     // Bits every taken gate requires to be 1 (only useful above the lane bits and
     // outside the register tile): fold them into the tile enumeration so that the
     // untouched part of the state is never read.
@@ -474,18 +509,19 @@ class Planner {
     }
     regmask = 0;
     for (int p : regs) regmask |= 1ull << p;
-    common &= ~lanemask & ~regmask & ((1ull << nloc_) - 1);
+    common &= ~lanemask & ~regmask & ~wavemask & ((1ull << nloc_) - 1);
     // keep enough free bits for the tile: need rb register bits among non-fixed bits
     int rb = std::max<int>((int)regs.size(), std::min(rb_cap_, any_dense ? rb_cap_ : 3));
-    while (popc(common) > 0 && nloc_ - kLaneBits - popc(common) < rb) common &= common - 1;
-    while (popc(common) + rb + kLaneHi > kMaxInsertBits) common &= common - 1;  // the rest stay per-op controls
-    rb = std::min(rb, nloc_ - kLaneBits - popc(common));
+    const int nwv = (int)waves.size();
+    while (popc(common) > 0 && nloc_ - kLaneBits - popc(common) - nwv < rb) common &= common - 1;
+    while (popc(common) + rb + kLaneHi + nwv > kMaxInsertBits) common &= common - 1;  // the rest stay per-op controls
+    rb = std::min(rb, nloc_ - kLaneBits - popc(common) - nwv);
     sp.fixed_ones = common;
     // pad the register tile with free bits: 10..13 first (a tile whose spare register
     // bits sit there streams ~10% faster than with bits 6..9 next to contiguous lanes
     // or with bits >= 18: tools/geom_scan.py), then the lowest free ones
     auto pad = [&](int p) {
-      if ((int)regs.size() < rb && p >= kLaneLow && p < nloc_ && !((regmask | common | lanemask) >> p & 1ull)) {
+      if ((int)regs.size() < rb && p >= kLaneLow && p < nloc_ && !((regmask | common | lanemask | wavemask) >> p & 1ull)) {
         regs.push_back(p);
         regmask |= 1ull << p;
       }
@@ -496,6 +532,8 @@ class Planner {
     sp.rb = (int)regs.size();
     for (int k = 0; k < sp.rb; ++k) sp.regpos[k] = regs[k];
     for (int k = 0; k < kLaneHi; ++k) sp.lanehi[k] = lanehi[k];
+    sp.nwave = nwv;
+    for (int k = 0; k < nwv; ++k) sp.wavepos[k] = waves[k];
     sp.ntiles = 1ull << (nloc_ - kLaneBits - sp.rb - popc(common));
     sp.swept_bytes = (sp.ntiles << (kLaneBits + sp.rb)) * amp_bytes_ * 2;
     emit_ops(taken, &sp);
@@ -504,6 +542,11 @@ class Planner {
 
   int reg_index(const SweepPlan &sp, int pos) const {
     for (int k = 0; k < sp.rb; ++k) if (sp.regpos[k] == pos) return k;
+    return -1;
+  }
+
+  static int wave_index(const SweepPlan &sp, int pos) {
+    for (int k = 0; k < sp.nwave; ++k) if (sp.wavepos[k] == pos) return k;
     return -1;
   }
 
@@ -551,6 +594,8 @@ class Planner {
     double lds = 0, valu = 0;
     int n01 = 0, n23 = 0, n45 = 0;
     for (const SweepOp &o : sp.ops) {
+      if (o.kind == OP_WSWAP) { lds += 256 * dw; continue; }   // 16 ds_write_b128 + 16 ds_read_b128, 8 cycles each
+      if (o.kind == OP_LSWAP) { valu += 128 * dw; continue; }
       if (o.kind == OP_DIAG) {
         bool c_part = false;
         for (uint32_t gi = 0; gi < o.n_groups; ++gi) {
@@ -596,7 +641,7 @@ class Planner {
     LaneChoice ch = choose_lane_paths(*sp);
     if (lane_valu_ == 2) ch.dpp01 = ch.dpp23 = ch.lswap = 1 << 20;
     if (ch.dpp01 + ch.dpp23 + ch.lswap == 0) return;
-    sp->ops.clear(); sp->groups.clear(); sp->oterms.clear(); sp->tables.clear();
+    sp->ops.clear(); sp->groups.clear(); sp->oterms.clear(); sp->tables.clear(); sp->ltabs.clear();
     emit_ops_with(taken, sp, ch);
   }
 
@@ -627,7 +672,9 @@ class Planner {
     geom.fixed_ones = sp->fixed_ones;
     memcpy(geom.regpos, sp->regpos, sizeof geom.regpos);
     memcpy(geom.lanehi, sp->lanehi, sizeof geom.lanehi);
-    std::vector<int> swaps;                       // lane bits exchanged so far (undone in reverse)
+    geom.nwave = sp->nwave;
+    memcpy(geom.wavepos, sp->wavepos, sizeof geom.wavepos);
+    std::vector<int> swaps;                       // layout exchanges so far (undone in reverse): lane bit li, or 16 + wave bit
     auto lswap = [&](int li) {
       SweepOp op{};
       op.kind = OP_LSWAP;
@@ -635,8 +682,19 @@ class Planner {
       sp->ops.push_back(op);
       std::swap(geom.lanehi[li - kLaneLow], geom.regpos[0]);
     };
+    auto wswap = [&](int wi) {
+      SweepOp op{};
+      op.kind = OP_WSWAP;
+      op.tb = (uint32_t)wi;
+      op.cm_thread = (1ull << geom.wavepos[wi]) | (1ull << geom.regpos[0]);
+      sp->ops.push_back(op);
+      std::swap(geom.wavepos[wi], geom.regpos[0]);
+    };
     auto restore_layout = [&]() {
-      while (!swaps.empty()) { lswap(swaps.back()); swaps.pop_back(); }
+      while (!swaps.empty()) {
+        if (swaps.back() >= 16) wswap(swaps.back() - 16); else lswap(swaps.back());
+        swaps.pop_back();
+      }
     };
     std::vector<PTerm> pending;
     auto add_pending = [&](uint64_t mask, double re, double im) {
@@ -652,6 +710,23 @@ class Planner {
       const GateRec *r = taken[gi];
       const bool diag = plan_diag(r->g, r->tgt);
       if (!diag) {
+        // a target that lives in the wave id comes into register bit 0 first: the phases
+        // waiting for this gate are then in-tile factors instead of one group per partner bit
+        int wi = wave_index(geom, r->tgt);
+        if (wi >= 0) {
+          // (the index-bit bookkeeping of OP_WSWAP assumes register bit 0 holds a register
+          // bit of the ORIGINAL lane map: undo lane exchanges first)
+          bool lane_swapped = false;
+          for (int e : swaps) lane_swapped |= e < 16;
+          if (lane_swapped) {
+            restore_layout();
+            wi = wave_index(geom, r->tgt);
+          }
+        }
+        if (wi >= 0) {
+          wswap(wi);
+          swaps.push_back(16 + wi);
+        }
         const size_t n_ops_before = sp->ops.size();
         flush_diag(&pending, 1ull << r->tgt, sp, geom);
         // non-zero only when THIS flush emitted a DIAG op right in front of the dense op
@@ -659,9 +734,13 @@ class Planner {
         SweepOp op{};
         uint32_t lane, reg; uint64_t outside, lane_phys;
         split_mask(geom, r->ctl_mask, &lane, &lane_phys, &reg, &outside);
-        if (lane && !swaps.empty()) {
-          // lane-bit controls are tested against the thread's ORIGINAL index bits
+        bool lane_swapped = false;
+        for (int e : swaps) lane_swapped |= e < 16;
+        if (lane && lane_swapped) {
+          // lane-bit controls are tested against the thread's ORIGINAL lane -> index-bit map
           restore_layout();
+          const int wj = wave_index(geom, r->tgt);
+          if (wj >= 0) { wswap(wj); swaps.push_back(16 + wj); }
           n_ops_after_flush = 0;
           split_mask(geom, r->ctl_mask, &lane, &lane_phys, &reg, &outside);
         }
@@ -726,6 +805,15 @@ class Planner {
     }
     flush_diag(&pending, ~0ull, sp, geom);
     restore_layout();
+    // lane tables go to the front of `tables` (one contiguous block: the kernel copies it to LDS)
+    const uint32_t nlt = (uint32_t)(sp->ltabs.size() / 2);
+    if (nlt) {
+      for (auto &g : sp->groups)
+        for (uint32_t t = 0; t < g.ntab; ++t) g.tab_off[t] += nlt;
+      sp->tables.insert(sp->tables.begin(), sp->ltabs.begin(), sp->ltabs.end());
+      sp->ltabs.clear();
+    }
+    sp->n_ltab = (int)(nlt / 64);
   }
 
   static void cmul_acc(double *re, double *im, double fr, double fi) {
@@ -770,7 +858,7 @@ class Planner {
         std::vector<OTerm> in;
         for (auto &o : pg.single) if (o.mask & cmask) in.push_back(o);
         if (in.empty()) continue;
-        if (g.ntab == 4 || in.size() < 2) {  // no table slot left / not worth a table
+        if (g.ntab == 4 || (int)in.size() < min_table_terms_) {  // no table slot left / not worth a table
           for (auto &o : in) loop_terms.push_back(o);
           continue;
         }
@@ -808,13 +896,13 @@ class Planner {
       g.reg_mask = groups[i].reg;
       g.re = 1; g.im = 0;
       g.flags = DG_LTAB;
-      g.ltab_off = (uint32_t)(sp->tables.size() / 2);
+      g.ltab_off = (uint32_t)(sp->ltabs.size() / 2);
       for (uint32_t lane = 0; lane < 64; ++lane) {
         double fr = 1, fi = 0;
         for (size_t j : lane_only)
           if ((lane & groups[j].lane) == groups[j].lane) cmul_acc(&fr, &fi, groups[j].re, groups[j].im);
-        sp->tables.push_back(fr);
-        sp->tables.push_back(fi);
+        sp->ltabs.push_back(fr);
+        sp->ltabs.push_back(fi);
       }
       for (size_t j : lane_only) done[j] = true;
       if (uniform >= 0) {
@@ -850,7 +938,7 @@ inline std::string plan_to_json(const std::vector<GateRec> &queue, int nloc, uin
     int nd = 0, ndiag = 0, nbf = 0;
     int nswap = 0, ndpp = 0;
     for (auto &o : sp.ops) {
-      if (o.kind == OP_LSWAP) { nswap++; continue; }
+      if (o.kind == OP_LSWAP || o.kind == OP_WSWAP) { nswap++; continue; }
       (o.kind == OP_DIAG ? ndiag : nd)++;
       if (o.flags & OPF_BFLY) nbf++;
       if (o.flags & OPF_LANE_DPP) ndpp++;
@@ -859,6 +947,8 @@ inline std::string plan_to_json(const std::vector<GateRec> &queue, int nloc, uin
     for (int k = 0; k < sp.rb; ++k) rp += (k ? "," : "") + std::to_string(sp.regpos[k]);
     rp += "],\"lanehi\":[";
     for (int k = 0; k < kLaneHi; ++k) rp += (k ? "," : "") + std::to_string(sp.lanehi[k]);
+    rp += "],\"wavepos\":[";
+    for (int k = 0; k < sp.nwave; ++k) rp += (k ? "," : "") + std::to_string(sp.wavepos[k]);
     rp += "]";
     snprintf(buf, sizeof buf,
              "%s{\"gates\":%llu,\"dense_ops\":%d,\"butterfly_ops\":%d,\"dpp_ops\":%d,\"lswap_ops\":%d,\"diag_ops\":%d,\"groups\":%zu,\"oterms\":%zu,\"table_entries\":%zu,"

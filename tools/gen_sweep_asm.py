@@ -29,6 +29,7 @@ Data layouts must match planner.h (SweepOp 96 B, DGroup 64 B, OTerm 24 B) and
 kernels_sweep.hip.h (SweepParams: slot byte offsets at +0x40).
 """
 import os
+import re
 import sys
 
 # streaming tile loads/stores are non-temporal (each byte is touched once per sweep)
@@ -178,6 +179,8 @@ def gen(rb, wide=True):
   a(f's_cbranch_scc1 {L("L_diag")}')
   a('s_cmp_eq_u32 s44, 3')                    # OP_LSWAP: exchange lane bit 4/5 with register bit 0
   a(f's_cbranch_scc1 {L("L_lswap")}')
+  a('s_cmp_eq_u32 s44, 4')                    # OP_WSWAP: exchange a wave bit with register bit 0 (through LDS)
+  a(f's_cbranch_scc1 {L("L_wswap")}')
   a('s_bitcmp1_b32 s51, 3')                   # OPF_BFLY: uncontrolled unit-entry butterfly
   a(f's_cbranch_scc1 {L("L_bf")}')
   # control predicate of this thread: (it & cm_thread) == cm_thread  -> s[68:69]
@@ -487,6 +490,58 @@ def gen(rb, wide=True):
         a(f'{ins} v{T(k) + d}, v{T(k + 1) + d}')
     a(f's_branch {L("L_next")}')
 
+
+  # ---- OP_WSWAP: wave bit tb <-> register bit 0 ------------------------------------------
+  # The 2^W waves of a workgroup hold the tiles of ONE super-tile: they differ in W chosen
+  # index bits ("wave bits").  A dense gate on such a bit pairs amplitudes of two waves; the
+  # exchange below transposes that bit with register bit 0: the wave whose bit is 0 hands its
+  # odd slots to the partner wave and receives the partner's even slots into them (and vice
+  # versa), through a 2^W x (half x 16 lines) LDS buffer, `half` slots per pass, two barriers
+  # per pass.  Afterwards the gate is a register op; the planner swaps back before the store.
+  # The wave's own index bits change with the layout: header field cm_thread holds
+  # (1 << old wave-bit position) | (1 << position of register bit 0); it is XORed into the
+  # tile index and the thread index when this wave's bit is 1.
+  a.label('L_wswap')
+  half = min(8, nr // 2)
+  slot_bytes = 64 * 4 * W() * 2 // 2            # bytes one slot of one wave takes (64 lanes x complex)
+  slot_bytes = 64 * 2 * W() * 4
+  region = half * slot_bytes
+  a('s_lshr_b32 s74, %8, s45')
+  a('s_and_b32 s74, s74, 1')                    # x = this wave's bit
+  a('s_lshl_b32 s75, 1, s45')
+  a('s_xor_b32 s75, %8, s75')                   # partner wave
+  a(f's_mul_i32 s72, %8, {region}')
+  a('s_add_u32 s72, s72, %9')
+  a(f's_mul_i32 s73, s75, {region}')
+  a('s_add_u32 s73, s73, %9')
+  a(f'v_lshlrev_b32 v16, {2 + W()}, %5')        # lane * bytes per amplitude
+  a('v_add_u32 v17, s72, v16')                  # where this wave writes
+  a('v_add_u32 v18, s73, v16')                  # where the partner wrote
+  a('s_cmp_eq_u32 s74, 0')
+  a(f's_cbranch_scc0 {L("L_wswap_even")}')
+  wr = 'ds_write_b128' if DT.wide else 'ds_write_b64'
+  rd = 'ds_read_b128' if DT.wide else 'ds_read_b64'
+  for name, parity in (('L_wswap_odd', 1), ('L_wswap_even', 0)):
+    a.label(name)
+    slots = [k for k in range(nr) if (k & 1) == parity]
+    for p0 in range(0, len(slots), half):
+      part = slots[p0:p0 + half]
+      for j, k in enumerate(part):
+        a(f'{wr} v17, v[{T(k)}:{T(k) + 2 * W() - 1}] offset:{j * slot_bytes}')
+      a('s_waitcnt lgkmcnt(0)')
+      a('s_barrier')
+      for j, k in enumerate(part):
+        a(f'{rd} v[{T(k)}:{T(k) + 2 * W() - 1}], v18 offset:{j * slot_bytes}')
+      a('s_waitcnt lgkmcnt(0)')
+      a('s_barrier')
+    if parity == 1:
+      a(f's_branch {L("L_next")}')                # bit 0: index bits unchanged (both positions hold 0)
+    else:
+      a('s_xor_b64 %3, %3, s[48:49]')
+      a('v_xor_b32 %6, s48, %6')
+      a('v_xor_b32 %7, s49, %7')
+      a(f's_branch {L("L_next")}')
+
   # ---- butterfly on lane bit 0..3 with DPP partner fetch (OPF_LANE_DPP) -------------------
   # new.re = o.re + beta_re * q.re ; new.im = o.im + beta_im * q.im, q = partner value, or the
   # partner with re/im exchanged (flags bit 8; v / v^+).  beta = +-1 per lane: g[0..3] =
@@ -684,9 +739,16 @@ def gen(rb, wide=True):
   a('s_bitcmp1_b32 s60, 0')                    # LTAB: start the 1-KiB lane-table load early
   a(f's_cbranch_scc0 {L("L_g1")}')
   a('s_lshl_b32 s74, s61, 4')
+  a(f'v_lshlrev_b32 v{V_A}, 4, %5')             # 16-byte table entries, indexed by the LANE id
+  a('s_bitcmp1_b32 s60, 1')                    # DG_LTAB_LDS: the kernel copied the lane tables to LDS
+  a(f's_cbranch_scc0 {L("L_g0g")}')
+  a('s_add_u32 s74, s74, %[ltab]')
+  a(f'v_add_u32 v{V_A}, s74, v{V_A}')
+  a(f'ds_read_b128 v[{D_LTAB}:{D_LTAB + 3}], v{V_A}')
+  a(f's_branch {L("L_g1")}')
+  a.label('L_g0g')
   a('s_add_u32 s98, s48, s74')
   a('s_addc_u32 s99, s49, 0')
-  a(f'v_lshlrev_b32 v{V_A}, 4, %5')             # 16-byte table entries, indexed by the LANE id
   a(f'global_load_dwordx4 v[{D_LTAB}:{D_LTAB + 3}], v{V_A}, s[98:99]')
   a.label('L_g1')
   a('s_cmp_eq_u32 s62, 0')
@@ -732,7 +794,7 @@ def gen(rb, wide=True):
   a.label('L_grp_f')
   a('s_bitcmp1_b32 s60, 0')
   a(f's_cbranch_scc0 {L("L_g3")}')
-  a('s_waitcnt vmcnt(0)')                      # f = ltab[lane] * u
+  a('s_waitcnt vmcnt(0) lgkmcnt(0)')           # f = ltab[lane] * u
   if DT.wide:
     lt_r, lt_i = V2(D_LTAB), V2(D_LTAB + 2)
   else:
@@ -809,12 +871,16 @@ def gen(rb, wide=True):
 
   clob = ([f'v{i}' for i in range(TEMP_LO, T0 + 2 * W() * nr)] + [f's{i}' for i in range(36, 100)] +
           ['vcc', 'scc', 'memory'])
-  body = '\n'.join(f'    "{ln}\\n\\t"' for ln in a.lines)
+  names = {'0': 'blo', '1': 'bhi', '2': 'prm', '3': 'tidx', '4': 'voff', '5': 'lane', '6': 'itlo', '7': 'ithi',
+           '8': 'wave', '9': 'lds'}
+  lines = [re.sub(r'%(\d)(?!\d)', lambda m: '%[' + names[m.group(1)] + ']', ln) for ln in a.lines]
+  body = '\n'.join(f'    "{ln}\\n\\t"' for ln in lines)
   cl = ', '.join(f'"{c}"' for c in clob)
   return (f'// GENERATED by tools/gen_sweep_asm.py (RB={rb}, {"complex128" if DT.wide else "complex64"}) -- do not edit.\n'
           f'asm volatile(\n{body}\n'
-          '    :\n'
-          '    : "s"(base_lo), "s"(base_hi), "s"(prm), "s"(tile_idx), "v"(voff), "v"(lane_u), "v"(it_lo), "v"(it_hi)\n'
+          '    : [tidx] "+s"(tile_idx), [itlo] "+v"(it_lo), [ithi] "+v"(it_hi)\n'
+          '    : [blo] "s"(base_lo), [bhi] "s"(base_hi), [prm] "s"(prm), [voff] "v"(voff), [lane] "v"(lane_u),\n'
+          '      [wave] "s"(wave_s), [lds] "s"(lds_base), [ltab] "s"(lds_ltab)\n'
           f'    : {cl});\n')
 
 

@@ -10,7 +10,7 @@
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 
 typedef double v2d __attribute__((ext_vector_type(2)));
-struct Geom { int pos[8]; int sorted[8]; int rot; int nblk_bits; int xs, xd, xw; };
+struct Geom { int pos[8]; int sorted[10]; int nins; int rot; int nblk_bits; int xs, xd, xw; int nwave; int wpos[2]; };
 
 __global__ __launch_bounds__(256) void k_geom(v2d *__restrict__ p, uint64_t ntiles, Geom g) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -23,14 +23,14 @@ __global__ __launch_bounds__(256) void k_geom(v2d *__restrict__ p, uint64_t ntil
     const uint64_t m = (1ull << g.nblk_bits) - 1;
     bi = ((bi >> g.rot) | (bi << (g.nblk_bits - g.rot))) & m;
   }
-  const uint64_t w = bi * 4 + wave;
-  if (w >= ntiles) return;
+  const uint64_t w = g.nwave ? bi : bi * 4 + wave;
+  if (w >= (g.nwave ? (ntiles >> g.nwave) : ntiles)) return;
   uint64_t j = w << 3;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {           // insert a zero at each tile bit, ascending
+  for (int k = 0; k < g.nins; ++k) {           // insert a zero at each tile bit, ascending
     const uint64_t low = (1ull << g.sorted[k]) - 1;
     j = ((j & ~low) << 1) | (j & low);
   }
+  for (int k = 0; k < g.nwave; ++k) j |= (uint64_t)((wave >> k) & 1) << g.wpos[k];
   v2d a[32];
 #pragma unroll
   for (int k = 0; k < 32; ++k) {
@@ -62,13 +62,20 @@ int main(int argc, char **argv) {
   for (int a = 2; a < argc; ++a) {
     Geom g; int k = 0;
     char buf[256]; strncpy(buf, argv[a], 255); buf[255] = 0;
-    for (char *t = strtok(buf, ","); t && k < 8; t = strtok(nullptr, ",")) g.pos[k++] = atoi(t);
+    int all[10];
+    { char *cut = strpbrk(buf, ":^"); if (cut) *cut = 0; }
+    for (char *t = strtok(buf, ","); t && k < 10; t = strtok(nullptr, ",")) all[k++] = atoi(t);
+    g.nwave = k > 8 ? k - 8 : 0;
+    for (int q = 0; q < 8 && q < k; ++q) g.pos[q] = all[q];
+    for (int q = 0; q < g.nwave; ++q) g.wpos[q] = all[8 + q];
+    g.nins = 8 + g.nwave;
+    if (k > 8) k = 8;
     g.rot = 0; g.nblk_bits = nb - 13;
     g.xs = g.xd = g.xw = 0;
     if (k == 8) { char *c = strchr(argv[a], ':'); if (c) g.rot = atoi(c + 1); }
     { char *c = strchr(argv[a], '^'); if (c) sscanf(c + 1, "%d,%d,%d", &g.xs, &g.xd, &g.xw); }
     if (k != 8) { printf("bad geometry %s\n", argv[a]); continue; }
-    memcpy(g.sorted, g.pos, sizeof(g.pos)); std::sort(g.sorted, g.sorted + 8);
+    memcpy(g.sorted, g.pos, sizeof(g.pos)); for (int q = 0; q < g.nwave; ++q) g.sorted[8 + q] = g.wpos[q]; std::sort(g.sorted, g.sorted + g.nins);
     float best = 1e9f;
     for (int rep = 0; rep < 4; ++rep) {
       CK(hipEventRecord(e0));
