@@ -674,27 +674,50 @@ class Planner {
     memcpy(geom.lanehi, sp->lanehi, sizeof geom.lanehi);
     geom.nwave = sp->nwave;
     memcpy(geom.wavepos, sp->wavepos, sizeof geom.wavepos);
-    std::vector<int> swaps;                       // layout exchanges so far (undone in reverse): lane bit li, or 16 + wave bit
-    auto lswap = [&](int li) {
+    // layout exchanges so far (undone in reverse): kind (0 lane / 1 wave), its bit index, register bit
+    struct Swap { int wave, idx, r; };
+    std::vector<Swap> swaps;
+    auto lswap = [&](int li, int r) {
       SweepOp op{};
       op.kind = OP_LSWAP;
       op.tb = (uint32_t)li;
+      op.cm_reg = (uint32_t)r;
       sp->ops.push_back(op);
-      std::swap(geom.lanehi[li - kLaneLow], geom.regpos[0]);
+      std::swap(geom.lanehi[li - kLaneLow], geom.regpos[r]);
     };
-    auto wswap = [&](int wi) {
+    auto wswap = [&](int wi, int r) {
       SweepOp op{};
       op.kind = OP_WSWAP;
       op.tb = (uint32_t)wi;
-      op.cm_thread = (1ull << geom.wavepos[wi]) | (1ull << geom.regpos[0]);
+      op.cm_reg = (uint32_t)r;
+      op.cm_thread = (1ull << geom.wavepos[wi]) | (1ull << geom.regpos[r]);
       sp->ops.push_back(op);
-      std::swap(geom.wavepos[wi], geom.regpos[0]);
+      std::swap(geom.wavepos[wi], geom.regpos[r]);
     };
     auto restore_layout = [&]() {
       while (!swaps.empty()) {
-        if (swaps.back() >= 16) wswap(swaps.back() - 16); else lswap(swaps.back());
+        const Swap w = swaps.back();
+        if (w.wave) wswap(w.idx, w.r); else lswap(w.idx, w.r);
         swaps.pop_back();
       }
+    };
+    auto lane_swapped = [&]() {
+      for (const Swap &w : swaps) if (!w.wave) return true;
+      return false;
+    };
+    // the register bit to give up in an exchange: the one whose qubit is a dense target
+    // again LATEST among the gates of this sweep (never, if possible) -- Belady
+    size_t gi_now = 0;
+    auto victim_reg = [&]() {
+      int best = 0;
+      size_t best_next = 0;
+      for (int r = 0; r < geom.rb; ++r) {
+        size_t next = taken.size() + 1;
+        for (size_t j = gi_now + 1; j < taken.size(); ++j)
+          if (!plan_diag(taken[j]->g, taken[j]->tgt) && taken[j]->tgt == geom.regpos[r]) { next = j; break; }
+        if (next > best_next) { best_next = next; best = r; }
+      }
+      return best;
     };
     std::vector<PTerm> pending;
     auto add_pending = [&](uint64_t mask, double re, double im) {
@@ -712,20 +735,18 @@ class Planner {
       if (!diag) {
         // a target that lives in the wave id comes into register bit 0 first: the phases
         // waiting for this gate are then in-tile factors instead of one group per partner bit
+        gi_now = gi;
         int wi = wave_index(geom, r->tgt);
-        if (wi >= 0) {
-          // (the index-bit bookkeeping of OP_WSWAP assumes register bit 0 holds a register
-          // bit of the ORIGINAL lane map: undo lane exchanges first)
-          bool lane_swapped = false;
-          for (int e : swaps) lane_swapped |= e < 16;
-          if (lane_swapped) {
-            restore_layout();
-            wi = wave_index(geom, r->tgt);
-          }
+        if (wi >= 0 && lane_swapped()) {
+          // (the index-bit bookkeeping of OP_WSWAP assumes the register bits are register
+          // bits of the ORIGINAL lane map: undo lane exchanges first)
+          restore_layout();
+          wi = wave_index(geom, r->tgt);
         }
         if (wi >= 0) {
-          wswap(wi);
-          swaps.push_back(16 + wi);
+          const int vr = victim_reg();
+          wswap(wi, vr);
+          swaps.push_back(Swap{1, wi, vr});
         }
         const size_t n_ops_before = sp->ops.size();
         flush_diag(&pending, 1ull << r->tgt, sp, geom);
@@ -734,13 +755,15 @@ class Planner {
         SweepOp op{};
         uint32_t lane, reg; uint64_t outside, lane_phys;
         split_mask(geom, r->ctl_mask, &lane, &lane_phys, &reg, &outside);
-        bool lane_swapped = false;
-        for (int e : swaps) lane_swapped |= e < 16;
-        if (lane && lane_swapped) {
+        if (lane && lane_swapped()) {
           // lane-bit controls are tested against the thread's ORIGINAL lane -> index-bit map
           restore_layout();
           const int wj = wave_index(geom, r->tgt);
-          if (wj >= 0) { wswap(wj); swaps.push_back(16 + wj); }
+          if (wj >= 0) {
+            const int vr = victim_reg();
+            wswap(wj, vr);
+            swaps.push_back(Swap{1, wj, vr});
+          }
           n_ops_after_flush = 0;
           split_mask(geom, r->ctl_mask, &lane, &lane_phys, &reg, &outside);
         }
@@ -752,8 +775,9 @@ class Planner {
         const int bv = role[gi] == 1 ? butterfly_variant(r->g) : -1;
         if (bv >= 0 && li >= 4 && ch.lswap > 0) {   // lane bit 4/5 <-> register bit 0, then a register butterfly
           ch.lswap--;
-          lswap(li);
-          swaps.push_back(li);
+          const int vr = victim_reg();
+          lswap(li, vr);
+          swaps.push_back(Swap{0, li, vr});
           n_ops_after_flush = 0;
           li = -1;
         }

@@ -473,7 +473,7 @@ def gen(rb, wide=True):
   bf_lane('w')
 
 
-  # ---- OP_LSWAP: lane bit tb (4 or 5) <-> register bit 0, in place -----------------------
+  # ---- OP_LSWAP: lane bit tb (4 or 5) <-> register bit r (header field cm_reg), in place --
   # v_permlane{16,32}_swap exchanges the odd rows / upper half of one register with the even
   # rows / lower half of another: applied to slots (k, k^1) it moves the pair a lane-bit gate
   # acts on into ONE lane (registers k and k^1), i.e. afterwards that index bit is register
@@ -481,17 +481,24 @@ def gen(rb, wide=True):
   # register op in between and swaps back (the op is an involution).  No LDS traffic:
   # ds_bpermute issues once per ~6 cycles per CU, these run at VALU rate.
   a.label('L_lswap')
-  a('s_cmp_eq_u32 s45, 5')
-  a(f's_cbranch_scc1 {L("L_lswap32")}')
-  for name, ins in (('L_lswap16', 'v_permlane16_swap_b32'), ('L_lswap32', 'v_permlane32_swap_b32')):
-    a.label(name)
-    for k in range(0, nr, 2):
-      for d in range(2 * W()):
-        a(f'{ins} v{T(k) + d}, v{T(k + 1) + d}')
-    a(f's_branch {L("L_next")}')
+  for r in range(rb):
+    a(f's_cmp_eq_u32 s46, {r}')
+    a(f's_cbranch_scc1 {L(f"L_lswap_r{r}")}')
+  a(f's_branch {L("L_next")}')
+  for r in range(rb):
+    a.label(f'L_lswap_r{r}')
+    a('s_cmp_eq_u32 s45, 5')
+    a(f's_cbranch_scc1 {L(f"L_lswap32_r{r}")}')
+    for name, ins in ((f'L_lswap16_r{r}', 'v_permlane16_swap_b32'), (f'L_lswap32_r{r}', 'v_permlane32_swap_b32')):
+      a.label(name)
+      for k in range(nr):
+        if k & (1 << r):
+          continue
+        for d in range(2 * W()):
+          a(f'{ins} v{T(k) + d}, v{T(k | (1 << r)) + d}')
+      a(f's_branch {L("L_next")}')
 
-
-  # ---- OP_WSWAP: wave bit tb <-> register bit 0 ------------------------------------------
+  # ---- OP_WSWAP: wave bit tb <-> register bit r (header field cm_reg) --------------------
   # The 2^W waves of a workgroup hold the tiles of ONE super-tile: they differ in W chosen
   # index bits ("wave bits").  A dense gate on such a bit pairs amplitudes of two waves; the
   # exchange below transposes that bit with register bit 0: the wave whose bit is 0 hands its
@@ -517,30 +524,36 @@ def gen(rb, wide=True):
   a(f'v_lshlrev_b32 v16, {2 + W()}, %5')        # lane * bytes per amplitude
   a('v_add_u32 v17, s72, v16')                  # where this wave writes
   a('v_add_u32 v18, s73, v16')                  # where the partner wrote
-  a('s_cmp_eq_u32 s74, 0')
-  a(f's_cbranch_scc0 {L("L_wswap_even")}')
   wr = 'ds_write_b128' if DT.wide else 'ds_write_b64'
   rd = 'ds_read_b128' if DT.wide else 'ds_read_b64'
-  for name, parity in (('L_wswap_odd', 1), ('L_wswap_even', 0)):
-    a.label(name)
-    slots = [k for k in range(nr) if (k & 1) == parity]
-    for p0 in range(0, len(slots), half):
-      part = slots[p0:p0 + half]
-      for j, k in enumerate(part):
-        a(f'{wr} v17, v[{T(k)}:{T(k) + 2 * W() - 1}] offset:{j * slot_bytes}')
-      a('s_waitcnt lgkmcnt(0)')
-      a('s_barrier')
-      for j, k in enumerate(part):
-        a(f'{rd} v[{T(k)}:{T(k) + 2 * W() - 1}], v18 offset:{j * slot_bytes}')
-      a('s_waitcnt lgkmcnt(0)')
-      a('s_barrier')
-    if parity == 1:
-      a(f's_branch {L("L_next")}')                # bit 0: index bits unchanged (both positions hold 0)
-    else:
-      a('s_xor_b64 %3, %3, s[48:49]')
-      a('v_xor_b32 %6, s48, %6')
-      a('v_xor_b32 %7, s49, %7')
-      a(f's_branch {L("L_next")}')
+  for r in range(rb):
+    a(f's_cmp_eq_u32 s46, {r}')
+    a(f's_cbranch_scc1 {L(f"L_wswap_r{r}")}')
+  a(f's_branch {L("L_next")}')
+  for r in range(rb):
+    a.label(f'L_wswap_r{r}')
+    a('s_cmp_eq_u32 s74, 0')
+    a(f's_cbranch_scc0 {L(f"L_wswap_even_r{r}")}')
+    for name, parity in ((f'L_wswap_odd_r{r}', 1), (f'L_wswap_even_r{r}', 0)):
+      a.label(name)
+      slots = [k for k in range(nr) if ((k >> r) & 1) == parity]
+      for p0 in range(0, len(slots), half):
+        part = slots[p0:p0 + half]
+        for j, k in enumerate(part):
+          a(f'{wr} v17, v[{T(k)}:{T(k) + 2 * W() - 1}] offset:{j * slot_bytes}')
+        a('s_waitcnt lgkmcnt(0)')
+        a('s_barrier')
+        for j, k in enumerate(part):
+          a(f'{rd} v[{T(k)}:{T(k) + 2 * W() - 1}], v18 offset:{j * slot_bytes}')
+        a('s_waitcnt lgkmcnt(0)')
+        a('s_barrier')
+      if parity == 1:
+        a(f's_branch {L("L_next")}')                # bit 0: index bits unchanged (both positions hold 0)
+      else:
+        a('s_xor_b64 %3, %3, s[48:49]')
+        a('v_xor_b32 %6, s48, %6')
+        a('v_xor_b32 %7, s49, %7')
+        a(f's_branch {L("L_next")}')
 
   # ---- butterfly on lane bit 0..3 with DPP partner fetch (OPF_LANE_DPP) -------------------
   # new.re = o.re + beta_re * q.re ; new.im = o.im + beta_im * q.im, q = partner value, or the
