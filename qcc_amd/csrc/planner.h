@@ -579,7 +579,7 @@ class Planner {
   struct PTerm { uint64_t mask; double re, im; };
 
   // How many lane butterflies leave the LDS (ds_bpermute) path, by lane-bit class.
-  struct LaneChoice { int dpp01 = 0, dpp23 = 0, lswap = 0; };
+  struct LaneChoice { int dpp01 = 0, dpp23 = 0, lswap = 0, real01 = 0, real23 = 0; };
 
   // ds_bpermute_b32 issues once per ~6.1 cycles per CU (tools/membench/bpermbench: the LDS
   // pipe is shared by the four SIMDs), a VALU instruction once per ~1.18.  A sweep with many
@@ -592,7 +592,7 @@ class Planner {
     const double kLds = 6.1 * (amp_bytes_ == 16 ? 128 : 64), kValu = 1.18;
     const double dw = amp_bytes_ == 16 ? 1.0 : 0.5;
     double lds = 0, valu = 0;
-    int n01 = 0, n23 = 0, n45 = 0;
+    int n01 = 0, n23 = 0, n45 = 0, r01 = 0, r23 = 0;
     for (const SweepOp &o : sp.ops) {
       if (o.kind == OP_WSWAP) { lds += 256 * dw; continue; }   // 16 ds_write_b128 + 16 ds_read_b128, 8 cycles each
       if (o.kind == OP_LSWAP) { valu += 128 * dw; continue; }
@@ -612,8 +612,10 @@ class Planner {
       if (o.flags & OPF_BFLY) {
         valu += 64;
         if (lane) (o.tb < 2 ? n01 : o.tb < 4 ? n23 : n45)++;
-      } else if (o.flags & OPF_REAL) valu += lane ? 128 : 160;
-      else valu += lane ? 384 : 400;
+      } else if (o.flags & OPF_REAL) {
+        valu += lane ? 128 : 160;
+        if (lane && o.cm_reg == 0 && !(o.flags & OPF_USE_C) && o.tb < 4) (o.tb < 2 ? r01 : r23)++;
+      } else valu += lane ? 384 : 400;
     }
     valu *= kValu;
     LaneChoice ch;
@@ -627,8 +629,10 @@ class Planner {
       }
     };
     take(&n01, &ch.dpp01, 128);                 // 4 DPP moves per slot
+    take(&r01, &ch.real01, 128);                // real (x, cx, ry ...) lane ops: same fetch, same combine
     take(&n45, &ch.lswap, 256);                 // swap in + swap out, 64 double-rate instructions each
     take(&n23, &ch.dpp23, 256);                 // 8 DPP moves per slot
+    take(&r23, &ch.real23, 256);
     return ch;
   }
 
@@ -639,8 +643,8 @@ class Planner {
     emit_ops_with(taken, sp, LaneChoice{});
     if (!lane_valu_) return;
     LaneChoice ch = choose_lane_paths(*sp);
-    if (lane_valu_ == 2) ch.dpp01 = ch.dpp23 = ch.lswap = 1 << 20;
-    if (ch.dpp01 + ch.dpp23 + ch.lswap == 0) return;
+    if (lane_valu_ == 2) ch.dpp01 = ch.dpp23 = ch.lswap = ch.real01 = ch.real23 = 1 << 20;
+    if (ch.dpp01 + ch.dpp23 + ch.lswap + ch.real01 + ch.real23 == 0) return;
     sp->ops.clear(); sp->groups.clear(); sp->oterms.clear(); sp->tables.clear(); sp->ltabs.clear();
     emit_ops_with(taken, sp, ch);
   }
@@ -801,6 +805,15 @@ class Planner {
             if (bv >= 3) op.flags |= OPF_SWAP_RI;
             sp->ops.push_back(op);
             if (bv == 0) add_pending(1ull << r->tgt, -1.0, 0.0);
+            continue;
+          }
+        }
+        if (bv < 0 && (op.flags & OPF_REAL) && op.kind == OP_DENSE_LANE && op.tb < 4 && op.cm_reg == 0) {
+          int *budget = op.tb < 2 ? &ch.real01 : &ch.real23;   // real lane op: partner by DPP instead of LDS
+          if (*budget > 0) {
+            --*budget;
+            op.flags |= OPF_LANE_DPP;
+            sp->ops.push_back(op);
             continue;
           }
         }

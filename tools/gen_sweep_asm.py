@@ -197,6 +197,8 @@ def gen(rb, wide=True):
   a('s_or_b32 s74, s46, s73')
   a('s_cmp_eq_u32 s74, 0')
   a(f's_cbranch_scc0 {L("L_generic")}')
+  a('s_bitcmp1_b32 s51, 7')                   # OPF_LANE_DPP on a real lane op: partner by DPP, no LDS
+  a(f's_cbranch_scc1 {L("L_lrd")}')
   a('s_and_b64 exec, exec, s[68:69]')
   a(f's_cbranch_execz {L("L_next")}')
   a(f's_branch {L("L_real")}')
@@ -608,6 +610,64 @@ def gen(rb, wide=True):
           a(f'v_mov_b32_dpp v{Q + d}, v{TQ + d} {steps[1]} row_mask:0xf bank_mask:0xf')
       a(FMA() + f' {X(k)}, {bre}, {V2(Q)}, {X(k)}')
       a(FMA() + f' {Y(k)}, {bim}, {V2(Q + W())}, {Y(k)}')
+    a(f's_branch {L("L_next")}')
+
+
+  # ---- real 2x2 on lane bit 0..3, partner by DPP moves (OPF_LANE_DPP on a REAL lane op) ------
+  # new = ca*own + cb*partner; the control predicate is folded into the coefficients
+  # (ca = 1, cb = 0 where it fails), so EXEC stays full and the two-step DPP moves may pass
+  # through lanes the gate does not act on.
+  a.label('L_lrd')
+  a('s_lshl_b32 s74, 1, s45')
+  a(f'v_and_b32 v{LN_TMP}, s74, %5')
+  a(f'v_cmp_ne_u32 vcc, 0, v{LN_TMP}')
+  CA, CB, Q2, TQ2 = 18, 18 + 2 * W(), 24, 28
+  if DT.wide:
+    for v, (lo, hi) in ((CA, (52, 64)), (CB, (56, 60))):
+      for d in range(2):
+        a(f'v_mov_b32 v{v + d}, s{lo + d}')
+        a(f'v_mov_b32 v{LN_TMP}, s{hi + d}')
+        a(f'v_cndmask_b32 v{v + d}, v{v + d}, v{LN_TMP}, vcc')
+    # predicate fails: ca = 1.0, cb = 0.0
+    a(f'v_mov_b32 v{LN_TMP}, 0x3ff00000')
+    a(f'v_cndmask_b32 v{CA}, 0, v{CA}, s[68:69]')
+    a(f'v_cndmask_b32 v{CA + 1}, v{LN_TMP}, v{CA + 1}, s[68:69]')
+    a(f'v_cndmask_b32 v{CB}, 0, v{CB}, s[68:69]')
+    a(f'v_cndmask_b32 v{CB + 1}, 0, v{CB + 1}, s[68:69]')
+  else:
+    a(f'v_cvt_f32_f64 v{CA}, s[52:53]')
+    a(f'v_cvt_f32_f64 v{LN_TMP}, s[64:65]')
+    a(f'v_cndmask_b32 v{CA}, v{CA}, v{LN_TMP}, vcc')
+    a(f'v_cvt_f32_f64 v{CB}, s[56:57]')
+    a(f'v_cvt_f32_f64 v{LN_TMP}, s[60:61]')
+    a(f'v_cndmask_b32 v{CB}, v{CB}, v{LN_TMP}, vcc')
+    a(f'v_cndmask_b32 v{CA}, 1.0, v{CA}, s[68:69]')
+    a(f'v_cndmask_b32 v{CB}, 0, v{CB}, s[68:69]')
+  for tbv in range(4):
+    a(f's_cmp_eq_u32 s45, {tbv}')
+    a(f's_cbranch_scc1 {L(f"L_lrd{tbv}")}')
+  a(f's_branch {L("L_next")}')
+  ca2, cb2 = V2(CA), V2(CB)
+  for tbv in range(4):
+    a.label(f'L_lrd{tbv}')
+    a('s_nop 1')
+    steps = DPP1[tbv]
+    for k in range(nr):
+      nd = 2 * W()
+      if len(steps) == 1:
+        for d in range(nd):
+          a(f'v_mov_b32_dpp v{Q2 + d}, v{T(k) + d} {steps[0]} row_mask:0xf bank_mask:0xf')
+      else:
+        for d in range(nd):
+          a(f'v_mov_b32_dpp v{TQ2 + d}, v{T(k) + d} {steps[0]} row_mask:0xf bank_mask:0xf')
+        if nd < 3:
+          a('s_nop 1')
+        for d in range(nd):
+          a(f'v_mov_b32_dpp v{Q2 + d}, v{TQ2 + d} {steps[1]} row_mask:0xf bank_mask:0xf')
+      a(MUL() + f' {X(k)}, {ca2}, {X(k)}')
+      a(MUL() + f' {Y(k)}, {ca2}, {Y(k)}')
+      a(FMA() + f' {X(k)}, {cb2}, {V2(Q2)}, {X(k)}')
+      a(FMA() + f' {Y(k)}, {cb2}, {V2(Q2 + W())}, {Y(k)}')
     a(f's_branch {L("L_next")}')
 
   # ---- dense 2x2 on a lane bit: partner via ds_bpermute -------------------------------
