@@ -614,7 +614,7 @@ class Planner {
         if (lane) (o.tb < 2 ? n01 : o.tb < 4 ? n23 : n45)++;
       } else if (o.flags & OPF_REAL) {
         valu += lane ? 128 : 160;
-        if (lane && o.cm_reg == 0 && !(o.flags & OPF_USE_C) && o.tb < 4) (o.tb < 2 ? r01 : r23)++;
+        if (lane && !(o.flags & OPF_USE_C) && o.tb < 4) (o.tb < 2 ? r01 : r23)++;
       } else valu += lane ? 384 : 400;
     }
     valu *= kValu;
@@ -808,7 +808,7 @@ class Planner {
             continue;
           }
         }
-        if (bv < 0 && (op.flags & OPF_REAL) && op.kind == OP_DENSE_LANE && op.tb < 4 && op.cm_reg == 0) {
+        if (bv < 0 && (op.flags & OPF_REAL) && op.kind == OP_DENSE_LANE && op.tb < 4) {
           int *budget = op.tb < 2 ? &ch.real01 : &ch.real23;   // real lane op: partner by DPP instead of LDS
           if (*budget > 0) {
             --*budget;

@@ -193,15 +193,22 @@ def gen(rb, wide=True):
   # REAL fast paths: all four matrix entries real (x, ry, cx, ccx ...) and no REGISTER-bit
   # control.  Lane / outside-bit controls just narrow EXEC: the real paths update in place,
   # so disabled lanes keep their amplitudes (a gate pair always shares its predicate).
-  a('s_andn2_b32 s73, 4, s51')                # 0 iff OPF_REAL set
-  a('s_or_b32 s74, s46, s73')
-  a('s_cmp_eq_u32 s74, 0')
+  a('s_bitcmp1_b32 s51, 2')                   # OPF_REAL
   a(f's_cbranch_scc0 {L("L_generic")}')
   a('s_bitcmp1_b32 s51, 7')                   # OPF_LANE_DPP on a real lane op: partner by DPP, no LDS
   a(f's_cbranch_scc1 {L("L_lrd")}')
   a('s_and_b64 exec, exec, s[68:69]')
   a(f's_cbranch_execz {L("L_next")}')
-  a(f's_branch {L("L_real")}')
+  a('s_cmp_eq_u32 s46, 0')
+  a(f's_cbranch_scc1 {L("L_real")}')
+  # register-bit controls (ccx, ladders of multi_control): same in-place real arithmetic,
+  # slots whose index misses a control bit are skipped one by one
+  a('s_cmp_eq_u32 s44, 1')
+  a(f's_cbranch_scc1 {L("L_lane_real_c")}')
+  for b in range(rb):
+    a(f's_cmp_eq_u32 s45, {b}')
+    a(f's_cbranch_scc1 {L(f"L_rrc{b}")}')
+  a(f's_branch {L("L_next")}')
   a.label('L_generic')
   a('s_cmp_eq_u32 s44, 1')
   a(f's_cbranch_scc1 {L("L_lane")}')
@@ -319,8 +326,34 @@ def gen(rb, wide=True):
       if k + depth < nr:
         shuf_to(k + depth, buf)
 
+
+  for b in range(rb):                            # real gate on register bit b under register controls
+    a.label(f'L_rrc{b}')
+    load_matrix_f32()
+    ta, tb_ = V2(R_T[0]), V2(R_T[1])
+    for h in range(nr // 2):
+      k0 = ((h >> b) << (b + 1)) | (h & ((1 << b) - 1))
+      k1 = k0 | (1 << b)
+      skip = f'L_rrc{b}_{h}'
+      a(f's_andn2_b32 s74, s46, {k0}')
+      a('s_cmp_eq_u32 s74, 0')
+      a(f's_cbranch_scc0 {L(skip)}')
+      a(MUL() + f' {ta}, {g["g0r"]}, {X(k0)}')
+      a(MUL() + f' {tb_}, {g["g0r"]}, {Y(k0)}')
+      a(FMA() + f' {ta}, {g["g1r"]}, {X(k1)}, {ta}')
+      a(FMA() + f' {tb_}, {g["g1r"]}, {Y(k1)}, {tb_}')
+      a(MUL() + f' {X(k1)}, {g["g3r"]}, {X(k1)}')
+      a(MUL() + f' {Y(k1)}, {g["g3r"]}, {Y(k1)}')
+      a(FMA() + f' {X(k1)}, {g["g2r"]}, {X(k0)}, {X(k1)}')
+      a(FMA() + f' {Y(k1)}, {g["g2r"]}, {Y(k0)}, {Y(k1)}')
+      a(MOV() + f' {X(k0)}, {ta}')
+      a(MOV() + f' {Y(k0)}, {tb_}')
+      a.label(skip)
+    a(f's_branch {L("L_next")}')
+
   # lane bit, real: new = ca*mine + cb*other with real per-lane ca, cb -- 4 FP64 ops per slot
   a.label('L_lane_real')
+  a.label('L_lane_real_c')
   a('s_lshl_b32 s74, 1, s45')
   a(f'v_xor_b32 v{LN_ADDR}, s74, %5')
   a(f'v_lshlrev_b32 v{LN_ADDR}, 2, v{LN_ADDR}')
@@ -349,7 +382,20 @@ def gen(rb, wide=True):
     a(MUL() + f' {Y(k)}, {rca}, {Y(k)}')
     a(FMA() + f' {X(k)}, {rcb}, {pr}, {X(k)}')
     a(FMA() + f' {Y(k)}, {rcb}, {pi}, {Y(k)}')
+
+  def comb_real_c(k, pr, pi):                    # register-bit controls: combine only the selected slots
+    skip = f'L_lrc_{k}'
+    a(f's_andn2_b32 s74, s46, {k}')
+    a('s_cmp_eq_u32 s74, 0')
+    a(f's_cbranch_scc0 {L(skip)}')
+    comb_real(k, pr, pi)
+    a.label(skip)
+  a('s_cmp_eq_u32 s46, 0')
+  a(f's_cbranch_scc0 {L("L_lane_real_cc")}')
   lane_pipeline(24, 4, comb_real)
+  a(f's_branch {L("L_next")}')
+  a.label('L_lane_real_cc')
+  lane_pipeline(24, 4, comb_real_c)              # (all slots are shuffled: the pipeline's wait counts stay static)
   a(f's_branch {L("L_next")}')
 
   # ---- unit-entry butterflies (OPF_BFLY): the gate is c*M with M's entries in {1,-1,i,-i};
@@ -654,6 +700,10 @@ def gen(rb, wide=True):
     steps = DPP1[tbv]
     for k in range(nr):
       nd = 2 * W()
+      skip = f'L_lrd{tbv}_{k}'
+      a(f's_andn2_b32 s74, s46, {k}')             # register-bit controls: skip the slots they exclude
+      a('s_cmp_eq_u32 s74, 0')
+      a(f's_cbranch_scc0 {L(skip)}')
       if len(steps) == 1:
         for d in range(nd):
           a(f'v_mov_b32_dpp v{Q2 + d}, v{T(k) + d} {steps[0]} row_mask:0xf bank_mask:0xf')
@@ -668,6 +718,7 @@ def gen(rb, wide=True):
       a(MUL() + f' {Y(k)}, {ca2}, {Y(k)}')
       a(FMA() + f' {X(k)}, {cb2}, {V2(Q2)}, {X(k)}')
       a(FMA() + f' {Y(k)}, {cb2}, {V2(Q2 + W())}, {Y(k)}')
+      a.label(skip)
     a(f's_branch {L("L_next")}')
 
   # ---- dense 2x2 on a lane bit: partner via ds_bpermute -------------------------------
