@@ -228,7 +228,10 @@ class Planner {
   bool split_lanes_;   // allow lane bits 3..5 to sit on arbitrary index bits (8 free tile bits)
   bool butterflies_ = env_flag("QH_BFLY", true);        // unit-entry butterfly ops (emit_ops_with)
   size_t dense_weight_ = env_int("QH_PLAN_DENSE_W", 1);  // score of a dense gate when choosing tile bits (diagonal = 1)
-  int max_wave_ = std::max(0, std::min(kMaxWaveBits, env_int("QH_WAVE_BITS", kMaxWaveBits)));
+  // wave bits per tile: one by default (a workgroup of two waves; measured on the 30-qubit QFT:
+  // 21.3 ms with one, 22.2 ms with two -- the four-wave barrier waits for the slowest of four
+  // op streams -- and 24.6 ms without; supremacy 52.2 / 50.9 / 54.4 ms, Grover-34 1.03 / 1.03 / 1.07 s)
+  int max_wave_ = std::max(0, std::min(kMaxWaveBits, env_int("QH_WAVE_BITS", 1)));
   int min_table_terms_ = env_int("QH_MIN_TABLE_TERMS", 2);
   int lane_valu_ = env_int("QH_LANE_VALU", 1);          // 0 never, 1 by cost model (choose_lane_paths), 2 always (tests)
   bool defer_diag_ = env_flag("QH_DEFER_DIAG", true);   // see build_sweep

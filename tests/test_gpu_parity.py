@@ -409,3 +409,32 @@ def test_init_product_matches_kron(bw):
     # ... and a factor list that does not add up is rejected
     with pytest.raises(native.QhError):
       st.init_product([(3, 1), (5, 2)])
+
+
+@pytest.mark.parametrize('wave_bits', ['0', '2'])
+@pytest.mark.parametrize('n,ngates,seed', [(15, 400, 3), (18, 300, 7)])
+def test_super_tile_variants_vs_oracle(oracle, monkeypatch, wave_bits, n, ngates, seed):
+  """The default plan uses one wave bit per tile (workgroups of two waves exchanging through
+  LDS, OP_WSWAP); two wave bits (four waves) and none are the other supported shapes."""
+  monkeypatch.setenv('QH_WAVE_BITS', wave_bits)
+  rng = np.random.default_rng(seed)
+  pool = _gate_pool(rng)
+  ops, gs = [], []
+  for _ in range(ngates):
+    t = int(rng.integers(n))
+    g = pool[int(rng.integers(len(pool)))]
+    if rng.random() < 0.5:
+      ops.append((int((t + 1 + rng.integers(n - 1)) % n), t))
+    else:
+      ops.append((NO_CTL, t))
+    gs.append(np.asarray(g, dtype=np.complex128).reshape(4))
+  ops = np.array(ops, dtype=np.int32)
+  g8 = np.array(gs).view(np.float64).reshape(-1, 8)
+  psi0 = _rand_state(rng, n)
+  want = psi0.copy()
+  oracle.run_stream(want, n, ops, g8)
+  with device.DeviceState(n, 128, fusion=native.QH_FUSE_SWEEP) as st:
+    st.upload(psi0)
+    st.run_stream(ops, g8)
+    got = st.download()
+  assert np.max(np.abs(got - want)) <= 1e-11

@@ -37,3 +37,9 @@ for top in (10, 11, 12):
 run('H 11,12 only', isH & (tb >= 11) & (tb <= 12))
 run('H 6..12', isH & (tb >= 6) & (tb <= 12))
 run('H 6..12 + cu1 inside 6..12', (isH & (tb >= 6) & (tb <= 12)) | (~isH & (lo >= 6) & (hi <= 12)))
+H12 = isH & (tb <= 12)
+run('H 0..12 + cu1 among 0..10 only', H12 | (~isH & (hi <= 10)))
+run('H 0..12 + cu1 touching 11 or 12 only', H12 | (~isH & (hi >= 11) & (hi <= 12)))
+run('H 0..12 + cu1 (reg 6..10, 11|12) only', H12 | (~isH & (hi >= 11) & (hi <= 12) & (lo >= 6)))
+run('H 0..12 + cu1 (lane 0..5, 11|12) only', H12 | (~isH & (hi >= 11) & (hi <= 12) & (lo <= 5)))
+run('H 0..12 + cu1 (11,12) only', H12 | (~isH & (hi == 12) & (lo == 11)))
