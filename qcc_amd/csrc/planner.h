@@ -232,6 +232,7 @@ class Planner {
   // 21.3 ms with one, 22.2 ms with two -- the four-wave barrier waits for the slowest of four
   // op streams -- and 24.6 ms without; supremacy 52.2 / 50.9 / 54.4 ms, Grover-34 1.03 / 1.03 / 1.07 s)
   int max_wave_ = std::max(0, std::min(kMaxWaveBits, env_int("QH_WAVE_BITS", 1)));
+  bool lanes_high_ = env_flag("QH_LANES_HIGH", true);
   int min_table_terms_ = env_int("QH_MIN_TABLE_TERMS", 2);
   int lane_valu_ = env_int("QH_LANE_VALU", 1);          // 0 never, 1 by cost model (choose_lane_paths), 2 always (tests)
   bool defer_diag_ = env_flag("QH_DEFER_DIAG", true);   // see build_sweep
@@ -384,11 +385,26 @@ class Planner {
       waves->assign(other.end() - nw, other.end());
       other.resize(other.size() - nw);
     }
-    for (int k = 0; k < need_move; ++k)
-      if (other[k] > kMaxLaneHiBit) return false;   // lane offsets are 32-bit byte offsets
     *lanehi = low;
-    lanehi->insert(lanehi->end(), other.begin(), other.begin() + need_move);
-    regs->assign(other.begin() + need_move, other.end());
+    if (need_move > 0 && other[0] >= 17 && lanes_high_) {
+      // every candidate is above the 2-MiB page (each line of a load in another page anyway):
+      // then the HIGHEST bits (up to kMaxLaneHiBit: lane offsets are 32-bit byte offsets) make
+      // the better lane bits (tools/geom_scan_wave1.py, targets 21..29: 6.9 ms vs 7.25 ms)
+      std::vector<int> rest;
+      int moved = 0;
+      for (size_t k = other.size(); k-- > 0;) {
+        if (moved < need_move && other[k] <= kMaxLaneHiBit) { lanehi->push_back(other[k]); moved++; }
+        else rest.push_back(other[k]);
+      }
+      if (moved < need_move) return false;
+      std::sort(rest.begin(), rest.end());
+      *regs = rest;
+    } else {
+      for (int k = 0; k < need_move; ++k)
+        if (other[k] > kMaxLaneHiBit) return false;
+      lanehi->insert(lanehi->end(), other.begin(), other.begin() + need_move);
+      regs->assign(other.begin() + need_move, other.end());
+    }
     for (int b = kLaneLow; b < kLaneBits && (int)lanehi->size() < kLaneHi; ++b)   // spare slots: 3,4,5
       if (std::find(lanehi->begin(), lanehi->end(), b) == lanehi->end()) lanehi->push_back(b);
     std::sort(lanehi->begin(), lanehi->end());

@@ -44,7 +44,7 @@ def test_qft30_is_three_sweeps_and_accounts_every_gate():
   assert sw[0]['dense_ops'] == 12
   # sweeps 2, 3: split-lane tiles: the lowest new bit in the wave id, then lanes, the highest in registers
   assert sw[1]['wavepos'] == [12] and sw[1]['lanehi'] == [13, 14, 15] and sw[1]['regpos'] == [16, 17, 18, 19, 20]
-  assert sw[2]['wavepos'] == [21] and sw[2]['lanehi'] == [22, 23, 24] and sw[2]['regpos'] == [25, 26, 27, 28, 29]
+  assert sw[2]['wavepos'] == [21] and sw[2]['lanehi'] == [25, 26, 27] and sw[2]['regpos'] == [22, 23, 24, 28, 29]
   assert all(s['swept_bytes'] == 2 * S for s in sw)            # one read + one write each
   # all H but one per sweep run as add-only butterflies; the remaining one carries the scalars
   assert [s['butterfly_ops'] for s in sw] == [s['dense_ops'] - 1 for s in sw]

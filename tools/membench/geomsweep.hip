@@ -70,7 +70,7 @@ int main(int argc, char **argv) {
     for (int q = 0; q < g.nwave; ++q) g.wpos[q] = all[8 + q];
     g.nins = 8 + g.nwave;
     if (k > 8) k = 8;
-    g.rot = 0; g.nblk_bits = nb - 13;
+    g.rot = 0; g.nblk_bits = g.nwave ? nb - 11 - g.nwave : nb - 13;
     g.xs = g.xd = g.xw = 0;
     if (k == 8) { char *c = strchr(argv[a], ':'); if (c) g.rot = atoi(c + 1); }
     { char *c = strchr(argv[a], '^'); if (c) sscanf(c + 1, "%d,%d,%d", &g.xs, &g.xd, &g.xw); }
@@ -79,7 +79,7 @@ int main(int argc, char **argv) {
     float best = 1e9f;
     for (int rep = 0; rep < 4; ++rep) {
       CK(hipEventRecord(e0));
-      k_geom<<<dim3((unsigned)((ntiles + 3) / 4)), dim3(256)>>>(p, ntiles, g);
+      k_geom<<<dim3((unsigned)(g.nwave ? (ntiles >> g.nwave) : (ntiles + 3) / 4)), dim3(g.nwave ? (64 << g.nwave) : 256)>>>(p, ntiles, g);
       CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (rep && ms < best) best = ms;
     }
