@@ -166,15 +166,23 @@ def gen(rb, wide=True):
   a('s_load_dwordx2 s[40:41], %2, 0x10')  # oterms base
   a('s_load_dwordx2 s[42:43], %2, 0x18')  # s42 = ops remaining, s43 = tables - groups (bytes)
   tile_io(store=False)
+  a('s_load_dwordx8 s[28:35], s[36:37], 0x0')     # header of the first op
   a('s_waitcnt vmcnt(0)')
 
   # ---- op loop ----------------------------------------------------------------------
+  # The 32-byte op header (kind tb cm_reg n_groups cm_thread(2) group_off flags) of op i+1 is
+  # fetched into s[28:35] while op i runs: the scalar-load latency (hundreds of cycles behind
+  # the tile stream) is off the critical path.  The 64-byte matrix g[8] is loaded only by the
+  # op kinds that read it (most ops of a QFT or supremacy sweep do not).
   a.label('L_op')
   a('s_cmp_eq_u32 s42, 0')
   a(f's_cbranch_scc1 {L("L_done")}')
-  a('s_load_dwordx8 s[44:51], s[36:37], 0x0')    # kind tb cm_reg n_groups cm_thread(2) group_off flags
-  a('s_load_dwordx16 s[52:67], s[36:37], 0x20')  # g[8]
   a('s_waitcnt lgkmcnt(0)')
+  a('s_mov_b64 s[44:45], s[28:29]')
+  a('s_mov_b64 s[46:47], s[30:31]')
+  a('s_mov_b64 s[48:49], s[32:33]')
+  a('s_mov_b64 s[50:51], s[34:35]')
+  a('s_load_dwordx8 s[28:35], s[36:37], 0x60')   # next op's header (the buffer is padded: reading one past the end is harmless)
   a('s_cmp_eq_u32 s44, 2')
   a(f's_cbranch_scc1 {L("L_diag")}')
   a('s_cmp_eq_u32 s44, 3')                    # OP_LSWAP: exchange lane bit 4/5 with register bit 0
@@ -183,6 +191,7 @@ def gen(rb, wide=True):
   a(f's_cbranch_scc1 {L("L_wswap")}')
   a('s_bitcmp1_b32 s51, 3')                   # OPF_BFLY: uncontrolled unit-entry butterfly
   a(f's_cbranch_scc1 {L("L_bf")}')
+  a('s_load_dwordx16 s[52:67], s[36:37], 0x20')  # g[8]
   # control predicate of this thread: (it & cm_thread) == cm_thread  -> s[68:69]
   a(f'v_and_b32 v{V_A}, s48, %6')
   a(f'v_and_b32 v{V_B}, s49, %7')
@@ -190,6 +199,7 @@ def gen(rb, wide=True):
   a(f'v_cmp_eq_u32_e64 s[72:73], s49, v{V_B}')
   a('s_nop 1')
   a('s_and_b64 s[68:69], vcc, s[72:73]')
+  a('s_waitcnt lgkmcnt(0)')                   # g[8] (and the header prefetch)
   # REAL fast paths: all four matrix entries real (x, ry, cx, ccx ...) and no REGISTER-bit
   # control.  Lane / outside-bit controls just narrow EXEC: the real paths update in place,
   # so disabled lanes keep their amplitudes (a gate pair always shares its predicate).
@@ -505,6 +515,8 @@ def gen(rb, wide=True):
     a(f'v_cndmask_b32 v{c0}, 1.0, v{LN_TMP}, vcc')
   bf_lane('a')
   a.label('L_bfl_b')                               # yroot / yroot^+: beta = g[0] on the 0-lane, g[1] on the 1-lane
+  a('s_load_dwordx4 s[52:55], s[36:37], 0x20')
+  a('s_waitcnt lgkmcnt(0)')
   if DT.wide:
     for d in range(2):
       a(f'v_mov_b32 v{c0 + d}, s{52 + d}')
@@ -608,10 +620,12 @@ def gen(rb, wide=True):
   # partner with re/im exchanged (flags bit 8; v / v^+).  beta = +-1 per lane: g[0..3] =
   # beta_re(0-lane), beta_re(1-lane), beta_im(0-lane), beta_im(1-lane).
   a.label('L_dpp')
+  a('s_load_dwordx8 s[52:59], s[36:37], 0x20')     # beta_re, beta_im per lane half
   a('s_lshl_b32 s75, 1, s45')
   a(f'v_and_b32 v{LN_TMP}, s75, %5')
   a(f'v_cmp_ne_u32 vcc, 0, v{LN_TMP}')
   BRE, BIM, Q, TQ = 18, 18 + 2 * W(), 24, 28
+  a('s_waitcnt lgkmcnt(0)')
   if DT.wide:
     for v, (lo, hi) in ((BRE, (52, 54)), (BIM, (56, 58))):
       for d in range(2):
@@ -993,7 +1007,7 @@ def gen(rb, wide=True):
   tile_io(store=True)
   a('s_nop 0')
 
-  clob = ([f'v{i}' for i in range(TEMP_LO, T0 + 2 * W() * nr)] + [f's{i}' for i in range(36, 100)] +
+  clob = ([f'v{i}' for i in range(TEMP_LO, T0 + 2 * W() * nr)] + [f's{i}' for i in range(28, 100)] +
           ['vcc', 'scc', 'memory'])
   names = {'0': 'blo', '1': 'bhi', '2': 'prm', '3': 'tidx', '4': 'voff', '5': 'lane', '6': 'itlo', '7': 'ithi',
            '8': 'wave', '9': 'lds'}
