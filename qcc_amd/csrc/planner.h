@@ -127,6 +127,7 @@ struct SweepOp {
 struct SweepPlan {
   int rb = 0;                      // register bits used by the kernel instance
   int regpos[kMaxRegBits] = {0};   // ascending physical positions
+  int regpos_store[kMaxRegBits] = {0};  // register bits when the tile is stored (OP_WSWAPs are not undone)
   int lanehi[kLaneHi] = {3, 4, 5}; // ascending positions of lane bits 3,4,5 ({3,4,5} = contiguous 1-KiB runs)
   int nwave = 0;                   // wave bits: the 2^nwave waves of a workgroup hold the tiles differing in
   int wavepos[kMaxWaveBits] = {0}; // these index bits; a gate on one runs after OP_WSWAP moved it into registers
@@ -232,6 +233,7 @@ class Planner {
   // 21.3 ms with one, 22.2 ms with two -- the four-wave barrier waits for the slowest of four
   // op streams -- and 24.6 ms without; supremacy 52.2 / 50.9 / 54.4 ms, Grover-34 1.03 / 1.03 / 1.07 s)
   int max_wave_ = std::max(0, std::min(kMaxWaveBits, env_int("QH_WAVE_BITS", 1)));
+  bool store_swapped_ = env_flag("QH_STORE_SWAPPED", true);
   bool lanes_high_ = env_flag("QH_LANES_HIGH", true);
   int min_table_terms_ = env_int("QH_MIN_TABLE_TERMS", 2);
   int lane_valu_ = env_int("QH_LANE_VALU", 1);          // 0 never, 1 by cost model (choose_lane_paths), 2 always (tests)
@@ -860,7 +862,18 @@ class Planner {
       }
     }
     flush_diag(&pending, ~0ull, sp, geom);
-    restore_layout();
+    // Lane exchanges are undone (the lane -> address map of the store is fixed); wave
+    // exchanges are not: the tile is stored where its amplitudes now belong (own slot
+    // offsets, base corrected by the moved index bits) -- one LDS exchange less per wave bit.
+    // (only for tiles with contiguous lanes: with split lanes the exchanged layout is the
+    // slower store geometry -- 7.1 vs 6.75 ms on sweep 2 of the QFT -- and undoing wins)
+    const bool contiguous = sp->lanehi[0] == 3 && sp->lanehi[1] == 4 && sp->lanehi[2] == 5;
+    if (store_swapped_ && contiguous) {
+      while (!swaps.empty() && !swaps.back().wave) { lswap(swaps.back().idx, swaps.back().r); swaps.pop_back(); }
+    } else {
+      restore_layout();
+    }
+    memcpy(sp->regpos_store, geom.regpos, sizeof geom.regpos);
     // lane tables go to the front of `tables` (one contiguous block: the kernel copies it to LDS)
     const uint32_t nlt = (uint32_t)(sp->ltabs.size() / 2);
     if (nlt) {

@@ -147,13 +147,23 @@ def gen(rb, wide=True):
   batch = min(8, nr)
 
   def tile_io(store):
+    # the store uses its own slot offsets (+0x140) and a base corrected by the index bits
+    # OP_WSWAP moved between the wave id and the registers (they are not swapped back)
+    blo, bhi, table = ('s24', 's25', 0x140) if store else ('%0', '%1', 0x40)
+    if store:
+      a('s_mov_b64 s[72:73], %3')
+      a('s_sub_u32 s24, s72, s26')                # tile index now - tile index at load time
+      a('s_subb_u32 s25, s73, s27')
+      a(f's_lshl_b64 s[24:25], s[24:25], {2 + W()}')
+      a('s_add_u32 s24, s24, %0')
+      a('s_addc_u32 s25, s25, %1')
     for j in range(nr // batch):
-      a(f's_load_dwordx{2 * batch} s[52:{52 + 2 * batch - 1}], %2, {0x40 + 8 * batch * j}')
+      a(f's_load_dwordx{2 * batch} s[52:{52 + 2 * batch - 1}], %2, {table + 8 * batch * j}')
       a('s_waitcnt lgkmcnt(0)')
       for i in range(batch):
         k = batch * j + i
-        a(f's_add_u32 s98, %0, s{52 + 2 * i}')
-        a(f's_addc_u32 s99, %1, s{53 + 2 * i}')
+        a(f's_add_u32 s98, {blo}, s{52 + 2 * i}')
+        a(f's_addc_u32 s99, {bhi}, s{53 + 2 * i}')
         dw = 'dwordx4' if DT.wide else 'dwordx2'
         regs = f'v[{T(k)}:{T(k) + 2 * W() - 1}]'
         if store:
@@ -166,6 +176,7 @@ def gen(rb, wide=True):
   a('s_load_dwordx2 s[40:41], %2, 0x10')  # oterms base
   a('s_load_dwordx2 s[42:43], %2, 0x18')  # s42 = ops remaining, s43 = tables - groups (bytes)
   tile_io(store=False)
+  a('s_mov_b64 s[26:27], %3')                     # tile index at load time (see the store)
   a('s_load_dwordx8 s[28:35], s[36:37], 0x0')     # header of the first op
   a('s_waitcnt vmcnt(0)')
 
@@ -1007,7 +1018,7 @@ def gen(rb, wide=True):
   tile_io(store=True)
   a('s_nop 0')
 
-  clob = ([f'v{i}' for i in range(TEMP_LO, T0 + 2 * W() * nr)] + [f's{i}' for i in range(28, 100)] +
+  clob = ([f'v{i}' for i in range(TEMP_LO, T0 + 2 * W() * nr)] + [f's{i}' for i in range(24, 100)] +
           ['vcc', 'scc', 'memory'])
   names = {'0': 'blo', '1': 'bhi', '2': 'prm', '3': 'tidx', '4': 'voff', '5': 'lane', '6': 'itlo', '7': 'ithi',
            '8': 'wave', '9': 'lds'}
