@@ -675,20 +675,38 @@ class Planner {
     // into ONE uncontrolled dense gate of the sweep (a scalar commutes with everything) -- the
     // last one, which runs on the general path.  Without such a sink nothing is converted.
     std::vector<int8_t> role(taken.size(), 0);   // 1 = butterfly, 2 = sink
-    double pr = 1, pi = 0;
+    std::vector<double> sink_re(taken.size(), 1.0), sink_im(taken.size(), 0.0);
     {
-      int sink = -1, nbf = 0;
+      int last = -1, nbf = 0;
       std::vector<int> cand;
       for (size_t i = 0; i < taken.size(); ++i) {
         const GateRec *r = taken[i];
         if (plan_diag(r->g, r->tgt) || (r->ctl_mask & ~sp->fixed_ones)) continue;
-        sink = (int)i;
+        last = (int)i;
         if (butterflies_ && butterfly_variant(r->g) >= 0) cand.push_back((int)i);
       }
-      for (int i : cand) if (i != sink) nbf++;
+      for (int i : cand) if (i != last) nbf++;
       if (nbf >= 1) {
-        for (int i : cand) if (i != sink) { role[i] = 1; cmul_acc(&pr, &pi, taken[i]->g[0], taken[i]->g[1]); }
-        role[sink] = 2;
+        // Between two sinks the stored amplitudes are the true ones divided by the scalars
+        // moved so far (sqrt 2 per h / v / yroot): a butterfly becomes an intermediate sink
+        // before that factor leaves the comfortable range of the element type.
+        const double limit = amp_bytes_ == 16 ? 0x1p100 : 0x1p24;
+        double pr = 1, pi = 0, growth = 1;
+        for (int i : cand) {
+          if (i == last) continue;
+          const double mag = std::hypot(taken[i]->g[0], taken[i]->g[1]);
+          if (growth / mag > limit || growth / mag < 1.0 / limit) {
+            role[i] = 2;
+            sink_re[i] = pr; sink_im[i] = pi;
+            pr = 1; pi = 0; growth = 1;
+            continue;
+          }
+          role[i] = 1;
+          cmul_acc(&pr, &pi, taken[i]->g[0], taken[i]->g[1]);
+          growth /= mag;
+        }
+        role[last] = 2;
+        sink_re[last] = pr; sink_im[last] = pi;
       }
     }
     // current tile geometry: OP_LSWAP exchanges a lane bit with register bit 0 on the fly
@@ -795,7 +813,7 @@ class Planner {
         op.cm_thread = outside | lane_phys;   // tested against the thread's physical index
         op.cm_reg = reg;
         memcpy(op.g, r->g, sizeof op.g);
-        if (role[gi] == 2) for (int k = 0; k < 4; ++k) cmul_acc(&op.g[2 * k], &op.g[2 * k + 1], pr, pi);
+        if (role[gi] == 2) for (int k = 0; k < 4; ++k) cmul_acc(&op.g[2 * k], &op.g[2 * k + 1], sink_re[gi], sink_im[gi]);
         int li = lane_index(geom, r->tgt);
         const int bv = role[gi] == 1 ? butterfly_variant(r->g) : -1;
         if (bv >= 0 && li >= 4 && ch.lswap > 0) {   // lane bit 4/5 <-> register bit 0, then a register butterfly

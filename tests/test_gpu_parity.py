@@ -438,3 +438,27 @@ def test_super_tile_variants_vs_oracle(oracle, monkeypatch, wave_bits, n, ngates
     st.run_stream(ops, g8)
     got = st.download()
   assert np.max(np.abs(got - want)) <= 1e-11
+
+
+@pytest.mark.parametrize('bw', [64, 128])
+def test_long_butterfly_runs_stay_in_range(oracle, bw):
+  """Hundreds of h / v / yroot in ONE sweep: their scalars are moved into sink gates, so the
+  stored amplitudes drift by sqrt(2) per gate in between -- intermediate sinks keep them in
+  the range of the element type (found by tools/fuzz_parity.py: complex64 overflowed)."""
+  n, ngates = 11, 600
+  dt = np.complex128 if bw == 128 else np.complex64
+  rng = np.random.default_rng(2024)
+  pool = [gates.hadamard(), gates.vgate(), gates.yroot()]
+  psi0 = _rand_state(rng, n, dt)
+  want = psi0.copy()
+  with device.DeviceState(n, bw, fusion=native.QH_FUSE_SWEEP) as st:
+    st.upload(psi0)
+    for _ in range(ngates):
+      g = np.asarray(pool[int(rng.integers(3))], dtype=np.complex128).reshape(4)
+      t = int(rng.integers(n))
+      oracle.apply1(want, g.astype(dt), n, t)
+      st.apply1(g, t)
+    got = st.download()
+    assert st.stats()['sweeps'] == 1
+  assert np.all(np.isfinite(got))
+  assert np.max(np.abs(got - want)) <= (1e-11 if bw == 128 else 2e-4)
