@@ -39,9 +39,10 @@ def pools(rng):
 
 
 def one_case(rng, case):
-  n = int(rng.integers(7, 22))
+  n = int(rng.integers(7, 22)) if rng.random() < 0.9 else int(rng.integers(22, 25))
   bw = 128 if rng.random() < 0.8 else 64
-  ngates = int(rng.integers(20, 500))
+  ngates = int(rng.integers(20, 500)) if n < 22 else int(rng.integers(20, 120))
+  gsh = int(rng.integers(0, 3)) if n >= 10 and rng.random() < 0.3 else 0   # shard bits (top qubits 0..gsh-1)
   w = rng.dirichlet([1, 1, 1, 1])              # butterfly / diagonal / real / general mix
   pctl = rng.uniform(0, 0.8)
   pmulti = rng.uniform(0, 0.3)
@@ -58,6 +59,8 @@ def one_case(rng, case):
     g = [bf, diag, real, gen][kind]
     g = np.asarray(g[int(rng.integers(len(g)))], dtype=np.complex128).reshape(4)
     t = int(rng.choice(hot)) if focus and rng.random() < 0.8 else int(rng.integers(n))
+    if t < gsh and kind != 1:
+      t = gsh + t % (n - gsh)                   # dense gates stay on local qubits (the exchange layer is tested elsewhere)
     ctl = []
     if rng.random() < pctl:
       k = 1 + (int(rng.integers(1, 4)) if rng.random() < pmulti else 0)
@@ -79,15 +82,20 @@ def one_case(rng, case):
       tmp = want.copy()
       orc.apply1(tmp, gq, n, t)
       want[mask] = tmp[mask]
-  with device.DeviceState(n, bw, fusion=native.QH_FUSE_SWEEP) as st:
-    st.upload(psi)
-    for ctl, t, g in stream:
-      cm = 0
-      for c in ctl:
-        cm |= 1 << (n - 1 - c)
-      st.apply_bits(cm, n - 1 - t, g)
-    got = st.download()
-    s = st.stats()
+  nloc = n - gsh
+  got = np.empty_like(psi)
+  for shard in range(1 << gsh):                 # every shard of the state on its own handle, one after the other
+    with device.DeviceState(nloc, bw, fusion=native.QH_FUSE_SWEEP) as st:
+      if gsh:
+        st.set_shard(n, shard)
+      st.upload(psi[shard << nloc: (shard + 1) << nloc])
+      for ctl, t, g in stream:
+        cm = 0
+        for c in ctl:
+          cm |= 1 << (n - 1 - c)
+        st.apply_bits(cm, n - 1 - t, g)
+      got[shard << nloc: (shard + 1) << nloc] = st.download()
+      s = st.stats()
   err = float(np.max(np.abs(got - want)))
   tol = 2e-11 if bw == 128 else 2e-4 * max(1.0, ngates / 100)
   ok = err <= tol
