@@ -853,6 +853,51 @@ int qh_plan_json(qh_handle h, char *buf, uint64_t cap, uint64_t *needed) {
   return QH_OK;
 }
 
+int qh_plan_export(qh_handle h, void *buf, uint64_t cap, uint64_t *needed) {
+  if (!h) return fail(QH_ERR_ARG, "null");
+  if (!qh::sweep_supported(h->nloc, h->bw)) return fail(QH_ERR_ARG, "state too small for sweeps");
+  qh::Planner pl(h->nloc, h->shard, h->bw, qh::sweep_max_rb(), qh::sweep_split_lanes() && h->bw == 128);
+  qh::PlanResult pr = pl.plan(h->queue);
+  std::vector<uint64_t> out;
+  auto put_bytes = [&](const void *p, size_t n) {
+    const size_t w = (n + 7) / 8, at = out.size();
+    out.resize(at + w, 0);
+    if (n) memcpy(&out[at], p, n);
+  };
+  out.push_back(0x51485031ull);
+  out.push_back(pr.sweeps.size());
+  out.push_back(pr.noop_gates);
+  for (auto &sp : pr.sweeps) {
+    int64_t hdr[24] = {0};
+    int k = 0;
+    hdr[k++] = sp.rb;
+    for (int i = 0; i < 5; ++i) hdr[k++] = sp.regpos[i];
+    for (int i = 0; i < 5; ++i) hdr[k++] = sp.regpos_store[i];
+    for (int i = 0; i < 3; ++i) hdr[k++] = sp.lanehi[i];
+    hdr[k++] = sp.nwave;
+    for (int i = 0; i < 2; ++i) hdr[k++] = sp.wavepos[i];
+    hdr[k++] = (int64_t)sp.fixed_ones;
+    hdr[k++] = (int64_t)sp.ntiles;
+    hdr[k++] = (int64_t)sp.ops.size();
+    hdr[k++] = (int64_t)sp.groups.size();
+    hdr[k++] = (int64_t)sp.oterms.size();
+    hdr[k++] = (int64_t)sp.tables.size();
+    hdr[k++] = sp.n_ltab;
+    put_bytes(hdr, sizeof hdr);
+    put_bytes(sp.ops.data(), sp.ops.size() * sizeof(qh::SweepOp));
+    put_bytes(sp.groups.data(), sp.groups.size() * sizeof(qh::DGroup));
+    put_bytes(sp.oterms.data(), sp.oterms.size() * sizeof(qh::OTerm));
+    put_bytes(sp.tables.data(), sp.tables.size() * sizeof(double));
+  }
+  const uint64_t bytes = out.size() * 8;
+  if (needed) *needed = bytes;
+  if (buf && cap) {
+    if (cap < bytes) return fail(QH_ERR_ARG, "buffer too small (call with NULL to get the size)");
+    memcpy(buf, out.data(), bytes);
+  }
+  return QH_OK;
+}
+
 // ---- literal drop-in on host buffers ------------------------------------------
 static qh_handle g_host_h = nullptr;
 

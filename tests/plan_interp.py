@@ -1,0 +1,152 @@
+"""Executes a sweep plan (qh_plan_export) with NumPy: TEST INFRASTRUCTURE.
+
+The planner (qcc_amd/csrc/planner.h) turns a queue of gates into sweeps of ops over a tile
+geometry; the GPU kernel interprets those ops on registers.  This module interprets the SAME
+ops on a whole state vector in physical index space, so that `-m "not gpu"` tests can check
+the planner's semantics (commutation, lazy diagonals, tables, butterfly scalars, layout
+exchanges, fixed bits, shard predicates) against the oracle without a GPU.  It never runs in
+the product path and shares no code with the kernel."""
+import ctypes
+
+import numpy as np
+
+from qcc_amd import native
+
+OP_DENSE_REG, OP_DENSE_LANE, OP_DIAG, OP_LSWAP, OP_WSWAP = 0, 1, 2, 3, 4
+OPF_REAL, OPF_BFLY, OPF_LANE_DPP, OPF_SWAP_RI = 4, 8, 128, 256
+DG_LTAB = 1
+
+OP_DT = np.dtype([('kind', '<u4'), ('tb', '<u4'), ('cm_reg', '<u4'), ('n_groups', '<u4'), ('cm_thread', '<u8'),
+                  ('group_off', '<u4'), ('flags', '<u4'), ('g', '<f8', (8,))])
+GROUP_DT = np.dtype([('lane_mask', '<u4'), ('reg_mask', '<u4'), ('oterm_off', '<u4'), ('n_oterms', '<u4'),
+                     ('re', '<f8'), ('im', '<f8'), ('flags', '<u4'), ('ltab_off', '<u4'), ('ntab', '<u4'),
+                     ('tab_shift', '<u4'), ('tab_off', '<u4', (4,))])
+OTERM_DT = np.dtype([('mask', '<u8'), ('re', '<f8'), ('im', '<f8')])
+assert OP_DT.itemsize == 96 and GROUP_DT.itemsize == 64 and OTERM_DT.itemsize == 24
+
+# unit-entry butterfly matrices (planner.h butterfly_variant), WITHOUT their scalar
+_BFLY = [np.array(m, dtype=np.complex128) for m in
+         ([[1, 1], [1, -1]], [[1, -1], [1, 1]], [[1, 1], [-1, 1]], [[1, -1j], [-1j, 1]], [[1, 1j], [1j, 1]])]
+
+
+def export_plan(handle):
+  lib = native.load()
+  need = ctypes.c_uint64()
+  native.check(lib.qh_plan_export(handle, None, 0, ctypes.byref(need)))
+  buf = np.zeros(need.value // 8, dtype=np.uint64)
+  native.check(lib.qh_plan_export(handle, buf.ctypes.data, need.value, None))
+  assert buf[0] == 0x51485031
+  nsweeps, noop = int(buf[1]), int(buf[2])
+  raw = buf.view(np.uint8)
+  pos = 24
+  sweeps = []
+  for _ in range(nsweeps):
+    hdr = raw[pos:pos + 192].view('<i8')
+    pos += 192
+    sp = {'rb': int(hdr[0]), 'regpos': [int(x) for x in hdr[1:6]], 'regpos_store': [int(x) for x in hdr[6:11]],
+          'lanehi': [int(x) for x in hdr[11:14]], 'nwave': int(hdr[14]), 'wavepos': [int(x) for x in hdr[15:17]],
+          'fixed_ones': int(hdr[17]) & (2 ** 64 - 1), 'ntiles': int(hdr[18]), 'n_ltab': int(hdr[23])}
+    for name, dt, count in (('ops', OP_DT, int(hdr[19])), ('groups', GROUP_DT, int(hdr[20])),
+                            ('oterms', OTERM_DT, int(hdr[21])), ('tables', np.dtype('<f8'), int(hdr[22]))):
+      nbytes = count * dt.itemsize
+      sp[name] = raw[pos:pos + nbytes].view(dt).copy()
+      pos += (nbytes + 7) // 8 * 8
+    sweeps.append(sp)
+  assert pos == raw.size
+  return sweeps, noop
+
+
+def _bit(idx, b):
+  return ((idx >> np.uint64(b)) & np.uint64(1)).astype(bool)
+
+
+def run_plan(psi, sweeps, nloc, shard=0):
+  """Apply the exported sweeps to the LOCAL shard `psi` (2^nloc amplitudes, physical order) in place."""
+  n = 1 << nloc
+  idx = np.arange(n, dtype=np.uint64)
+  gidx = idx | (np.uint64(shard) << np.uint64(nloc))          # global index (shard bits on top)
+  for sp in sweeps:
+    rb = sp['rb']
+    regpos = list(sp['regpos'][:rb])
+    lanepos = [0, 1, 2] + list(sp['lanehi'])
+    wavepos = list(sp['wavepos'][:sp['nwave']])
+    fixed = np.uint64(sp['fixed_ones'])
+    in_sweep = (idx & fixed) == fixed
+    tab = sp['tables'].view(np.complex128)
+
+    def coords():
+      lane = np.zeros(n, dtype=np.uint64)
+      for k, b in enumerate(lanepos):
+        lane |= ((idx >> np.uint64(b)) & np.uint64(1)) << np.uint64(k)
+      slot = np.zeros(n, dtype=np.uint64)
+      m = 0
+      for k, b in enumerate(regpos):
+        slot |= ((idx >> np.uint64(b)) & np.uint64(1)) << np.uint64(k)
+        m |= 1 << b
+      for b in lanepos:
+        m |= 1 << b
+      tile = gidx & ~np.uint64(m)                               # what the kernel calls the tile index
+      return lane, slot, tile
+
+    for op in sp['ops']:
+      kind, tb, flags = int(op['kind']), int(op['tb']), int(op['flags'])
+      if kind == OP_LSWAP:
+        r = int(op['cm_reg'])
+        lanepos[tb], regpos[r] = regpos[r], lanepos[tb]
+        continue
+      if kind == OP_WSWAP:
+        r = int(op['cm_reg'])
+        assert int(op['cm_thread']) == (1 << wavepos[tb]) | (1 << regpos[r])
+        wavepos[tb], regpos[r] = regpos[r], wavepos[tb]
+        continue
+      lane, slot, tile = coords()
+      if kind == OP_DIAG:
+        factor = np.ones(n, dtype=np.complex128)
+        for g in sp['groups'][int(op['group_off']): int(op['group_off']) + int(op['n_groups'])]:
+          u = np.full(n, complex(g['re'], g['im']))
+          for t in range(int(g['ntab'])):
+            sh = (int(g['tab_shift']) >> (8 * t)) & 0xff
+            u = u * tab[int(g['tab_off'][t]) + ((tile >> np.uint64(sh)) & np.uint64(0xff)).astype(np.int64)]
+          for ot in sp['oterms'][int(g['oterm_off']): int(g['oterm_off']) + int(g['n_oterms'])]:
+            m = np.uint64(ot['mask'])
+            u = np.where((tile & m) == m, u * complex(ot['re'], ot['im']), u)
+          if int(g['flags']) & DG_LTAB:
+            f = tab[int(g['ltab_off']) + lane.astype(np.int64)] * u
+          else:
+            lm = np.uint64(g['lane_mask'])
+            f = np.where((lane & lm) == lm, u, 1.0)
+          rm = np.uint64(g['reg_mask'])
+          factor = np.where((slot & rm) == rm, factor * f, factor)
+        psi[in_sweep] = (psi * factor.astype(psi.dtype))[in_sweep]
+        continue
+      # dense ops
+      tgt = lanepos[tb] if kind == OP_DENSE_LANE else regpos[tb]
+      cm_reg = np.uint64(op['cm_reg'])
+      ok = in_sweep & ((slot & cm_reg) == cm_reg) & ((gidx & np.uint64(op['cm_thread'])) == np.uint64(op['cm_thread']))
+      g8 = op['g']
+      if flags & OPF_BFLY:
+        v = (flags >> 4) & 7
+        if flags & OPF_LANE_DPP:
+          # new.re = own.re + b_re*q.re ; new.im = own.im + b_im*q.im ; q = partner (re/im exchanged if SWAP_RI)
+          hi = _bit(idx, tgt)
+          partner = psi[idx ^ np.uint64(1 << tgt)]
+          q = (partner.imag + 1j * partner.real) if flags & OPF_SWAP_RI else partner
+          bre = np.where(hi, g8[1], g8[0])
+          bim = np.where(hi, g8[3], g8[2])
+          new = (psi.real + bre * q.real) + 1j * (psi.imag + bim * q.imag)
+          psi[ok] = new.astype(psi.dtype)[ok]
+          continue
+        m = _BFLY[v]
+      else:
+        m = g8.view(np.complex128).reshape(2, 2)
+      lo = ok & ~_bit(idx, tgt)
+      i0 = idx[lo]
+      i1 = i0 | np.uint64(1 << tgt)
+      a, b = psi[i0].astype(np.complex128), psi[i1].astype(np.complex128)
+      psi[i0] = (m[0, 0] * a + m[0, 1] * b).astype(psi.dtype)
+      psi[i1] = (m[1, 0] * a + m[1, 1] * b).astype(psi.dtype)
+    # the tile is stored with `regpos_store`; lane exchanges must have been undone
+    assert lanepos == [0, 1, 2] + list(sp['lanehi']), 'lane layout not restored before the store'
+    assert regpos == list(sp['regpos_store'][:rb]), 'store layout disagrees with the exported one'
+    assert sorted(regpos + wavepos) == sorted(list(sp['regpos'][:rb]) + list(sp['wavepos'][:sp['nwave']]))
+  return psi

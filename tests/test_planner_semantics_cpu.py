@@ -1,0 +1,117 @@
+"""The planner's output executed on the CPU (tests/plan_interp.py) against the oracle: random
+circuits, every plan shape the engine can be switched to, single and sharded handles.  No GPU."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from qcc_amd import gates, native, workloads
+from tests import plan_interp
+from tests.oracle_lib import NO_CTL
+
+_dp = ctypes.POINTER(ctypes.c_double)
+
+
+def _rand_unitary(rng):
+  m = rng.standard_normal((2, 2)) + 1j * rng.standard_normal((2, 2))
+  q, r = np.linalg.qr(m)
+  return q * (np.diag(r) / np.abs(np.diag(r)))
+
+
+def _stream(rng, n, ngates, gshard=0):
+  v, yr, h = gates.vgate(), gates.yroot(), gates.hadamard()
+  pool = [h, yr, v, np.conj(np.asarray(yr).reshape(2, 2).T), np.conj(np.asarray(v).reshape(2, 2).T),
+          gates.tgate(), gates.sgate(), gates.pauli_z(), gates.u1(0.37), gates.rz(0.9), gates.pauli_x(),
+          gates.ry(0.8), gates.rx(0.4), gates.pauli_y(), _rand_unitary(rng)]
+  out = []
+  for _ in range(ngates):
+    g = np.asarray(pool[int(rng.integers(len(pool)))], dtype=np.complex128).reshape(4)
+    diag = g[1] == 0 and g[2] == 0
+    t = int(rng.integers(n))
+    if t < gshard and not diag:
+      t = gshard + t % (n - gshard)
+    ctl = []
+    if rng.random() < 0.5:
+      k = 1 + (int(rng.integers(1, 3)) if rng.random() < 0.25 else 0)
+      others = [q for q in range(n) if q != t]
+      ctl = [int(c) for c in rng.choice(others, size=k, replace=False)]
+    out.append((ctl, t, g))
+  return out
+
+
+def _oracle_apply(oracle, psi, n, stream):
+  idx = np.arange(1 << n, dtype=np.uint64)
+  for ctl, t, g in stream:
+    if not ctl:
+      oracle.apply1(psi, g, n, t)
+    elif len(ctl) == 1:
+      oracle.applyc(psi, g, n, ctl[0], t)
+    else:
+      mask = np.ones(1 << n, dtype=bool)
+      for c in ctl:
+        mask &= ((idx >> np.uint64(n - 1 - c)) & np.uint64(1)).astype(bool)
+      tmp = psi.copy()
+      oracle.apply1(tmp, g, n, t)
+      psi[mask] = tmp[mask]
+
+
+def _planned(n, nloc, shard, stream):
+  lib = native.load()
+  h = ctypes.c_void_p()
+  native.check(lib.qh_create_dry(nloc, 128, ctypes.byref(h)))
+  if nloc != n:
+    native.check(lib.qh_set_shard(h, n, shard))
+  native.check(lib.qh_set_fusion(h, native.QH_FUSE_SWEEP))
+  for ctl, t, g in stream:
+    cm = 0
+    for c in ctl:
+      cm |= 1 << (n - 1 - c)
+    g8 = np.ascontiguousarray(g).view(np.float64)
+    native.check(lib.qh_apply_bits(h, cm, n - 1 - t, g8.ctypes.data_as(_dp)))
+  sweeps, _ = plan_interp.export_plan(h)
+  lib.qh_destroy(h)
+  return sweeps
+
+
+ENVS = [{}, {'QH_WAVE_BITS': '2'}, {'QH_WAVE_BITS': '0'}, {'QH_LANE_VALU': '2'}, {'QH_LANE_VALU': '2', 'QH_WAVE_BITS': '2'},
+        {'QH_STORE_SWAPPED': '0'}, {'QH_DEFER_DIAG': '0', 'QH_BFLY': '0'}, {'QH_SWEEP_RB': '3'}, {'QH_SPLIT_LANES': '0'}]
+
+
+@pytest.mark.parametrize('env', ENVS, ids=lambda e: ','.join(f'{k[3:]}={v}' for k, v in e.items()) or 'default')
+def test_planned_sweeps_equal_the_oracle(oracle, monkeypatch, env):
+  for k, v in env.items():
+    monkeypatch.setenv(k, v)
+  rng = np.random.default_rng(hash(tuple(sorted(env.items()))) & 0xffff)
+  for case in range(14):
+    n = int(rng.integers(10, 16))
+    gshard = int(rng.integers(0, 3)) if case % 3 == 2 else 0
+    stream = _stream(rng, n, int(rng.integers(20, 220)), gshard)
+    psi = rng.standard_normal(1 << n) + 1j * rng.standard_normal(1 << n)
+    psi = (psi / np.linalg.norm(psi)).astype(np.complex128)
+    want = psi.copy()
+    _oracle_apply(oracle, want, n, stream)
+    nloc = n - gshard
+    got = np.empty_like(psi)
+    for shard in range(1 << gshard):
+      sweeps = _planned(n, nloc, shard, stream)
+      part = psi[shard << nloc: (shard + 1) << nloc].copy()
+      plan_interp.run_plan(part, sweeps, nloc, shard)
+      got[shard << nloc: (shard + 1) << nloc] = part
+    err = float(np.max(np.abs(got - want)))
+    assert err < 1e-11, (env, case, n, gshard, err)
+
+
+def test_reference_workload_plans_equal_the_oracle(oracle):
+  """QFT, supremacy and one Grover iteration at sizes the CPU handles: plan -> NumPy == oracle."""
+  for n, sb in ((14, workloads.qft_stream(range(14))), (14, workloads.supremacy_stream(14, 12, seed=3)),
+                (14, workloads.grover_stream(7, [1, 0, 1, 1, 0, 0, 1], iterations=1))):
+    ops, g8 = sb.arrays()
+    stream = [([] if c == NO_CTL else [int(c)], int(t), g.view(np.complex128).copy()) for (c, t), g in zip(ops, g8)]
+    rng = np.random.default_rng(5)
+    psi = rng.standard_normal(1 << n) + 1j * rng.standard_normal(1 << n)
+    psi = (psi / np.linalg.norm(psi)).astype(np.complex128)
+    want = psi.copy()
+    oracle.run_stream(want, n, ops, g8)
+    got = psi.copy()
+    plan_interp.run_plan(got, _planned(n, n, 0, stream), n)
+    assert np.max(np.abs(got - want)) < 1e-11
