@@ -23,6 +23,10 @@ def _stream(rng, n, ngates, gshard=0):
   pool = [h, yr, v, np.conj(np.asarray(yr).reshape(2, 2).T), np.conj(np.asarray(v).reshape(2, 2).T),
           gates.tgate(), gates.sgate(), gates.pauli_z(), gates.u1(0.37), gates.rz(0.9), gates.pauli_x(),
           gates.ry(0.8), gates.rx(0.4), gates.pauli_y(), _rand_unitary(rng)]
+  if rng.random() < 0.3:     # operators the reference also feeds through apply1 (projectors, ladder operators, scalings)
+    pool += [np.array([[1, 0], [0, 0]]), np.array([[0, 0], [0, 1]]), np.array([[0, 1], [0, 0]]), np.array([[0, 0], [1, 0]]),
+             np.array([[0.5, 0], [0, 2.0]]), np.array([[0, 0], [0, 0]]), np.array([[2.0, 0], [0, 2.0]]),
+             np.array([[1, 1], [1, 1]]) * 0.5]
   out = []
   for _ in range(ngates):
     g = np.asarray(pool[int(rng.integers(len(pool)))], dtype=np.complex128).reshape(4)

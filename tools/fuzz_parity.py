@@ -35,6 +35,9 @@ def pools(rng):
   diag = [gates.tgate(), gates.sgate(), gates.pauli_z(), gates.u1(rng.uniform(0, 6)), gates.rz(rng.uniform(0, 6))]
   real = [gates.pauli_x(), gates.ry(rng.uniform(0, 3)) if hasattr(gates, 'ry') else gates.hadamard()]
   gen = [rand_unitary(rng), gates.rx(rng.uniform(0, 3)), gates.pauli_y()]
+  if rng.random() < 0.25:   # non-unitary operators the reference also pushes through apply1
+    diag += [np.array([[1, 0], [0, 0]]), np.array([[0, 0], [0, 1]]), np.array([[0.5, 0], [0, 2.0]]), np.array([[0, 0], [0, 0]])]
+    gen += [np.array([[0, 1], [0, 0]]), np.array([[0, 0], [1, 0]]), np.array([[1, 1], [1, 1]]) * 0.5]
   return bf, diag, real, gen
 
 
