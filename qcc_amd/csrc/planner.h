@@ -55,8 +55,8 @@ constexpr int kMaxSweepOps = 1024;
 constexpr int kMaxInsertBits = 12;  // == kMaxIns of kernels_gate.hip.h (tile enumeration)
 
 enum : uint32_t { OP_DENSE_REG = 0, OP_DENSE_LANE = 1, OP_DIAG = 2,
-                  OP_LSWAP = 3,    // lane bit tb (4|5) <-> register bit 0 (v_permlane swaps)
-                  OP_WSWAP = 4 };  // wave bit tb <-> register bit 0 (through LDS); cm_thread = index bits that flip
+                  OP_LSWAP = 3,    // lane bit tb (4|5) <-> register bit cm_reg (v_permlane swaps)
+                  OP_WSWAP = 4 };  // wave bit tb <-> register bit cm_reg (through LDS); cm_thread = index bits that flip
 // A DIAG op directly followed by an uncontrolled dense op on a LANE bit does not
 // apply its per-lane factor c to the 2^RB slots: the dense op folds it into its
 // per-lane matrix coefficients (H.diag(c)), two complex products per lane.
@@ -606,7 +606,7 @@ class Planner {
   // pipe is shared by the four SIMDs), a VALU instruction once per ~1.18.  A sweep with many
   // lane-bit gates is therefore bound by the LDS pipe long before HBM (supremacy: 21 lane
   // ops -> 15 ms for a 6 ms sweep).  Lane butterflies can instead fetch the partner by DPP
-  // moves (lane bits 0..3) or exchange lane bit 4/5 with register bit 0 by
+  // moves (lane bits 0..3) or exchange lane bit 4/5 with a register bit by
   // v_permlane{16,32}_swap and run as register butterflies: more VALU work, no LDS.  The
   // split is chosen per sweep so that neither pipe exceeds the other (cycles per tile per CU).
   LaneChoice choose_lane_paths(const SweepPlan &sp) const {
@@ -709,7 +709,7 @@ class Planner {
         sink_re[last] = pr; sink_im[last] = pi;
       }
     }
-    // current tile geometry: OP_LSWAP exchanges a lane bit with register bit 0 on the fly
+    // current tile geometry: OP_LSWAP / OP_WSWAP exchange a lane / wave bit with a register bit on the fly
     SweepPlan geom;
     geom.rb = sp->rb;
     geom.fixed_ones = sp->fixed_ones;
@@ -776,7 +776,7 @@ class Planner {
       const GateRec *r = taken[gi];
       const bool diag = plan_diag(r->g, r->tgt);
       if (!diag) {
-        // a target that lives in the wave id comes into register bit 0 first: the phases
+        // a target that lives in the wave id comes into a register bit first: the phases
         // waiting for this gate are then in-tile factors instead of one group per partner bit
         gi_now = gi;
         int wi = wave_index(geom, r->tgt);
@@ -816,7 +816,7 @@ class Planner {
         if (role[gi] == 2) for (int k = 0; k < 4; ++k) cmul_acc(&op.g[2 * k], &op.g[2 * k + 1], sink_re[gi], sink_im[gi]);
         int li = lane_index(geom, r->tgt);
         const int bv = role[gi] == 1 ? butterfly_variant(r->g) : -1;
-        if (bv >= 0 && li >= 4 && ch.lswap > 0) {   // lane bit 4/5 <-> register bit 0, then a register butterfly
+        if (bv >= 0 && li >= 4 && ch.lswap > 0) {   // lane bit 4/5 <-> a register bit, then a register butterfly
           ch.lswap--;
           const int vr = victim_reg();
           lswap(li, vr);

@@ -196,9 +196,9 @@ def gen(rb, wide=True):
   a('s_load_dwordx8 s[28:35], s[36:37], 0x60')   # next op's header (the buffer is padded: reading one past the end is harmless)
   a('s_cmp_eq_u32 s44, 2')
   a(f's_cbranch_scc1 {L("L_diag")}')
-  a('s_cmp_eq_u32 s44, 3')                    # OP_LSWAP: exchange lane bit 4/5 with register bit 0
+  a('s_cmp_eq_u32 s44, 3')                    # OP_LSWAP: exchange lane bit 4/5 with a register bit
   a(f's_cbranch_scc1 {L("L_lswap")}')
-  a('s_cmp_eq_u32 s44, 4')                    # OP_WSWAP: exchange a wave bit with register bit 0 (through LDS)
+  a('s_cmp_eq_u32 s44, 4')                    # OP_WSWAP: exchange a wave bit with a register bit (through LDS)
   a(f's_cbranch_scc1 {L("L_wswap")}')
   a('s_bitcmp1_b32 s51, 3')                   # OPF_BFLY: uncontrolled unit-entry butterfly
   a(f's_cbranch_scc1 {L("L_bf")}')
@@ -548,7 +548,7 @@ def gen(rb, wide=True):
   # v_permlane{16,32}_swap exchanges the odd rows / upper half of one register with the even
   # rows / lower half of another: applied to slots (k, k^1) it moves the pair a lane-bit gate
   # acts on into ONE lane (registers k and k^1), i.e. afterwards that index bit is register
-  # bit 0 and the old register bit 0 is the lane bit.  The planner emits the gate as a
+  # bit r and the old register bit r is the lane bit.  The planner emits the gate as a
   # register op in between and swaps back (the op is an involution).  No LDS traffic:
   # ds_bpermute issues once per ~6 cycles per CU, these run at VALU rate.
   a.label('L_lswap')
@@ -572,12 +572,12 @@ def gen(rb, wide=True):
   # ---- OP_WSWAP: wave bit tb <-> register bit r (header field cm_reg) --------------------
   # The 2^W waves of a workgroup hold the tiles of ONE super-tile: they differ in W chosen
   # index bits ("wave bits").  A dense gate on such a bit pairs amplitudes of two waves; the
-  # exchange below transposes that bit with register bit 0: the wave whose bit is 0 hands its
-  # odd slots to the partner wave and receives the partner's even slots into them (and vice
+  # exchange below transposes that bit with register bit r: the wave whose bit is 0 hands its
+  # slots with bit r set to the partner wave and receives the partner's other slots into them (and vice
   # versa), through a 2^W x (half x 16 lines) LDS buffer, `half` slots per pass, two barriers
   # per pass.  Afterwards the gate is a register op; the planner swaps back before the store.
   # The wave's own index bits change with the layout: header field cm_thread holds
-  # (1 << old wave-bit position) | (1 << position of register bit 0); it is XORed into the
+  # (1 << old wave-bit position) | (1 << position of register bit r); it is XORed into the
   # tile index and the thread index when this wave's bit is 1.
   a.label('L_wswap')
   half = min(8, nr // 2)
