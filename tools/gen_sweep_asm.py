@@ -177,23 +177,23 @@ def gen(rb, wide=True):
   a('s_load_dwordx2 s[42:43], %2, 0x18')  # s42 = ops remaining, s43 = tables - groups (bytes)
   tile_io(store=False)
   a('s_mov_b64 s[26:27], %3')                     # tile index at load time (see the store)
-  a('s_load_dwordx8 s[28:35], s[36:37], 0x0')     # header of the first op
+  a('s_load_dwordx8 s[16:23], s[36:37], 0x0')     # header of the first op
   a('s_waitcnt vmcnt(0)')
 
   # ---- op loop ----------------------------------------------------------------------
   # The 32-byte op header (kind tb cm_reg n_groups cm_thread(2) group_off flags) of op i+1 is
-  # fetched into s[28:35] while op i runs: the scalar-load latency (hundreds of cycles behind
+  # fetched into s[16:23] while op i runs: the scalar-load latency (hundreds of cycles behind
   # the tile stream) is off the critical path.  The 64-byte matrix g[8] is loaded only by the
   # op kinds that read it (most ops of a QFT or supremacy sweep do not).
   a.label('L_op')
   a('s_cmp_eq_u32 s42, 0')
   a(f's_cbranch_scc1 {L("L_done")}')
   a('s_waitcnt lgkmcnt(0)')
-  a('s_mov_b64 s[44:45], s[28:29]')
-  a('s_mov_b64 s[46:47], s[30:31]')
-  a('s_mov_b64 s[48:49], s[32:33]')
-  a('s_mov_b64 s[50:51], s[34:35]')
-  a('s_load_dwordx8 s[28:35], s[36:37], 0x60')   # next op's header (the buffer is padded: reading one past the end is harmless)
+  a('s_mov_b64 s[44:45], s[16:17]')
+  a('s_mov_b64 s[46:47], s[18:19]')
+  a('s_mov_b64 s[48:49], s[20:21]')
+  a('s_mov_b64 s[50:51], s[22:23]')
+  a('s_load_dwordx8 s[16:23], s[36:37], 0x60')   # next op's header (the buffer is padded: reading one past the end is harmless)
   a('s_cmp_eq_u32 s44, 2')
   a(f's_cbranch_scc1 {L("L_diag")}')
   a('s_cmp_eq_u32 s44, 3')                    # OP_LSWAP: exchange lane bit 4/5 with a register bit
@@ -1018,7 +1018,7 @@ def gen(rb, wide=True):
   tile_io(store=True)
   a('s_nop 0')
 
-  clob = ([f'v{i}' for i in range(TEMP_LO, T0 + 2 * W() * nr)] + [f's{i}' for i in range(24, 100)] +
+  clob = ([f'v{i}' for i in range(TEMP_LO, T0 + 2 * W() * nr)] + [f's{i}' for i in range(16, 28)] + [f's{i}' for i in range(36, 100)] +
           ['vcc', 'scc', 'memory'])
   names = {'0': 'blo', '1': 'bhi', '2': 'prm', '3': 'tidx', '4': 'voff', '5': 'lane', '6': 'itlo', '7': 'ithi',
            '8': 'wave', '9': 'lds'}
