@@ -11,16 +11,17 @@ equal r, in its own HBM, behind its own engine handle.  Per gate:
                                             local diagonal gate / scalar, no
                                             communication (all 630 CU1 of a
                                             36-qubit QFT are in this class or local);
-  * dense gate whose TARGET is a shard bit -> the shard bit is swapped with the
-    top local bit: each rank exchanges the half of its shard whose top local bit
-    differs from its own shard bit with the partner rank r ^ 2^k (pairwise
-    send/recv, chunked through a staging buffer so no second copy of the shard is
-    ever needed), the logical->physical bit map is updated, and the gate -- and
-    every later gate on that qubit -- is local.  A 36-qubit QFT on 8 GPUs needs
-    exactly 3 such exchanges (the H gates on qubits 2, 1, 0).
+  * dense gate whose TARGET is a shard bit -> ONE exchange swaps all g shard bits with g
+    consecutive local bits: rank r sends block j of its shard to rank j and receives block r
+    of rank j's (grouped send/recv to all P-1 peers at once, so every xGMI link of the GPU
+    carries 1/P of the shard; chunked through a double-buffered staging area, in place), the
+    logical->physical bit map is updated, and the gate -- and every later gate on those
+    qubits -- is local.  WHICH local bits leave is chosen like a cache victim from the known
+    gate stream (Belady): a QFT repeated in a loop pays exactly one exchange per QFT.
+    (exchange='pairwise' keeps the one-bit variant: half a shard to rank r ^ 2^k over one link.)
 
-There is no collective on the data path other than that pairwise exchange;
-reductions (norm, arg-max) are 8-16 byte all-reduces.
+There is no collective on the data path other than that exchange; reductions (norm,
+arg-max) are 8-16 byte all-reduces / all-gathers.
 
 The local engine is qcc_amd.device.DeviceState attached to a torch CUDA tensor
 (so torch.distributed can address the same HBM).  Tests substitute a CPU engine
