@@ -843,7 +843,8 @@ int qh_timer_end(qh_handle h, float *ms) {
 
 int qh_plan_json(qh_handle h, char *buf, uint64_t cap, uint64_t *needed) {
   if (!h) return fail(QH_ERR_ARG, "null");
-  std::string s = qh::plan_to_json(h->queue, h->nloc, h->shard);
+  std::string s = qh::plan_to_json(h->queue, h->nloc, h->shard, h->bw, qh::sweep_max_rb(),
+                                   qh::sweep_split_lanes() && h->bw == 128);
   if (needed) *needed = s.size() + 1;
   if (buf && cap) {
     const uint64_t n = std::min<uint64_t>(cap - 1, s.size());
@@ -856,8 +857,8 @@ int qh_plan_json(qh_handle h, char *buf, uint64_t cap, uint64_t *needed) {
 int qh_plan_export(qh_handle h, void *buf, uint64_t cap, uint64_t *needed) {
   if (!h) return fail(QH_ERR_ARG, "null");
   if (!qh::sweep_supported(h->nloc, h->bw)) return fail(QH_ERR_ARG, "state too small for sweeps");
-  qh::Planner pl(h->nloc, h->shard, h->bw, qh::sweep_max_rb(), qh::sweep_split_lanes() && h->bw == 128);
-  qh::PlanResult pr = pl.plan(h->queue);
+  qh::PlanResult pr = qh::plan_best(h->queue, h->nloc, h->shard, h->bw, qh::sweep_max_rb(),
+                                    qh::sweep_split_lanes() && h->bw == 128);
   std::vector<uint64_t> out;
   auto put_bytes = [&](const void *p, size_t n) {
     const size_t w = (n + 7) / 8, at = out.size();

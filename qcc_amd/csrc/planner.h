@@ -164,9 +164,10 @@ inline uint64_t gate_alg_bytes(const GateRec &r, int nloc, uint64_t amp_bytes) {
 
 class Planner {
  public:
-  Planner(int nloc, uint64_t shard, int bw, int max_rb, bool split_lanes = true)
+  Planner(int nloc, uint64_t shard, int bw, int max_rb, bool split_lanes = true, int wave_bits = -1)
       : nloc_(nloc), shard_(shard), amp_bytes_(bw == 128 ? 16 : 8), split_lanes_(split_lanes) {
     rb_cap_ = std::min({max_rb, kMaxRegBits, nloc - kLaneBits});
+    if (wave_bits >= 0) max_wave_ = std::min(wave_bits, kMaxWaveBits);
   }
 
   PlanResult plan(const std::vector<GateRec> &queue) {
@@ -229,9 +230,7 @@ class Planner {
   bool split_lanes_;   // allow lane bits 3..5 to sit on arbitrary index bits (8 free tile bits)
   bool butterflies_ = env_flag("QH_BFLY", true);        // unit-entry butterfly ops (emit_ops_with)
   size_t dense_weight_ = env_int("QH_PLAN_DENSE_W", 1);  // score of a dense gate when choosing tile bits (diagonal = 1)
-  // wave bits per tile: one by default (a workgroup of two waves; measured on the 30-qubit QFT:
-  // 21.3 ms with one, 22.2 ms with two -- the four-wave barrier waits for the slowest of four
-  // op streams -- and 24.6 ms without; supremacy 52.2 / 50.9 / 54.4 ms, Grover-34 1.03 / 1.03 / 1.07 s)
+  // wave bits per tile (see plan_best): QH_WAVE_BITS pins it
   int max_wave_ = std::max(0, std::min(kMaxWaveBits, env_int("QH_WAVE_BITS", 1)));
   bool store_swapped_ = env_flag("QH_STORE_SWAPPED", true);
   bool lanes_high_ = env_flag("QH_LANES_HIGH", true);
@@ -1013,11 +1012,46 @@ class Planner {
   }
 };
 
+// The plan with the fewest sweeps over the wave-bit choices {1, 2, 0}, the earlier choice
+// winning ties.  Measured (ms): 30-qubit QFT 21.3 with one wave bit / 22.2 with two (same 3
+// sweeps: the four-wave barrier waits for the slowest of four op streams) / 24.6 without
+// (4 sweeps); supremacy-30 52 (6 sweeps) / 51 (5) / 54 (7); QFT-31 52 (4) / 44 (3); QFT-32
+// 104 (4) / 86 (3).  A plan is set aside if one of its tiles spreads over eight or more index
+// bits >= 25 -- every 128-byte line of a wave then sits in another 512-MiB region and the
+// sweep runs at half speed (QFT-33, two wave bits: 113 ms for the last sweep instead of 55).
+// Planning costs a few ms per attempt and runs while the previous flush is still executing.
+inline bool plan_has_far_tile(const PlanResult &pr) {
+  for (const SweepPlan &sp : pr.sweeps) {
+    int far = 0;
+    for (int k = 0; k < kLaneHi; ++k) far += sp.lanehi[k] >= 25;
+    for (int k = 0; k < sp.rb; ++k) far += sp.regpos[k] >= 25;
+    if (far >= 8) return true;
+  }
+  return false;
+}
+
+inline PlanResult plan_best(const std::vector<GateRec> &queue, int nloc, uint64_t shard, int bw, int max_rb,
+                            bool split_lanes) {
+  if (getenv("QH_WAVE_BITS")) return Planner(nloc, shard, bw, max_rb, split_lanes).plan(queue);
+  PlanResult best;
+  bool have = false, best_far = false;
+  for (int wb : {1, 2, 0}) {
+    PlanResult pr = Planner(nloc, shard, bw, max_rb, split_lanes, wb).plan(queue);
+    const bool far = plan_has_far_tile(pr);
+    if (!have || (best_far && !far) || (best_far == far && pr.sweeps.size() < best.sweeps.size())) {
+      best = std::move(pr);
+      best_far = far;
+      have = true;
+    }
+    if (best.sweeps.size() <= 1 && !best_far) break;
+  }
+  return best;
+}
+
 inline std::string plan_to_json(const std::vector<GateRec> &queue, int nloc, uint64_t shard, int bw = 128,
-                                int max_rb = kMaxRegBits) {
+                                int max_rb = kMaxRegBits, bool split_lanes = true) {
   if (nloc < kLaneBits + 2) return "{\"sweeps\":[],\"note\":\"state too small for sweeps\"}";
-  Planner pl(nloc, shard, bw, max_rb);
-  PlanResult pr = pl.plan(queue);
+  PlanResult pr = plan_best(queue, nloc, shard, bw, max_rb, split_lanes);
   std::string s = "{\"noop_gates\":" + std::to_string(pr.noop_gates) + ",\"sweeps\":[";
   char buf[384];
   for (size_t i = 0; i < pr.sweeps.size(); ++i) {

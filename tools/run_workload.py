@@ -18,6 +18,9 @@ elif name == 'grover34':
 elif name == 'qft30c64':
   n, init, bw = 30, 5, 64
   ops, g8 = workloads.qft_stream(range(30)).arrays()
+elif name.startswith('qft') and name[3:].isdigit():
+  n, init = int(name[3:]), 5
+  ops, g8 = workloads.qft_stream(range(n)).arrays()
 else:
   n, init = 30, 5
   ops, g8 = workloads.qft_stream(range(30)).arrays()
