@@ -30,6 +30,7 @@ struct GateRec {
   uint64_t ctl_mask;  // all these index bits must be 1
   int tgt;            // target bit
   double g[8];        // row-major 2x2, (re,im) pairs
+  uint64_t neg_mask = 0;  // all these index bits must be 0 (planner-internal: see propagate_x)
 };
 
 // The boundary only ever sees the four matrix entries: classify by
@@ -209,6 +210,7 @@ class Planner {
     std::vector<uint64_t> alg = alg_override_;
     std::vector<uint32_t> weight(pending.size(), 1);
     fuse_sleator_weinfurter(&pending, &alg, &weight);
+    if (propagate_x_) propagate_x(&pending, &alg, &weight, &out.noop_gates);
     weight_.swap(weight);
     while (!pending.empty()) {
       std::vector<GateRec> rest;
@@ -232,6 +234,7 @@ class Planner {
   size_t dense_weight_ = env_int("QH_PLAN_DENSE_W", 1);  // score of a dense gate when choosing tile bits (diagonal = 1)
   // wave bits per tile (see plan_best): QH_WAVE_BITS pins it
   int max_wave_ = std::max(0, std::min(kMaxWaveBits, env_int("QH_WAVE_BITS", 1)));
+  bool propagate_x_ = env_flag("QH_PROPAGATE_X", true);   // see propagate_x
   bool store_swapped_ = env_flag("QH_STORE_SWAPPED", true);
   bool lanes_high_ = env_flag("QH_LANES_HIGH", true);
   int min_table_terms_ = env_int("QH_MIN_TABLE_TERMS", 2);
@@ -250,6 +253,77 @@ class Planner {
     for (int i = 0; i < 8; ++i) if (g[i] != x[i]) return false;
     return true;
   }
+  // Uncontrolled X gates are not executed where they stand: an X on bit c is remembered as a
+  // pending flip of that bit and pushed through the following gates -- a control on c changes
+  // polarity (the reference wraps "controlled by |0>" as X.gate.X, circuit.py:166-169,207-215;
+  // multi_control and the Grover oracles do the same around whole ladders), a gate acting on c
+  // is conjugated (M -> X M X: rows and columns exchanged) -- and is emitted only at the end
+  // of the flush if it is still pending.  Fewer dense gates, and bits that only ever saw X
+  // need no place in a tile.
+  void propagate_x(std::vector<GateRec> *pending, std::vector<uint64_t> *alg, std::vector<uint32_t> *weight,
+                   uint64_t *noops) const {
+    std::vector<GateRec> out;
+    std::vector<uint64_t> oalg;
+    std::vector<uint32_t> ow;
+    uint64_t flip = 0, carry_alg = 0;
+    uint32_t carry_w = 0;
+    auto emit_x = [&](int bit) {
+      GateRec x{};
+      x.ctl_mask = 0;
+      x.tgt = bit;
+      x.g[2] = 1.0; x.g[4] = 1.0;
+      out.push_back(x);
+      oalg.push_back(carry_alg);
+      ow.push_back(carry_w);
+      carry_alg = 0;
+      carry_w = 0;
+    };
+    for (size_t i = 0; i < pending->size(); ++i) {
+      GateRec r = (*pending)[i];
+      if (r.tgt >= 0 && r.ctl_mask == 0 && r.neg_mask == 0 && is_x(r.g)) {
+        flip ^= 1ull << r.tgt;
+        carry_alg += (*alg)[i];
+        carry_w += (*weight)[i];
+        continue;
+      }
+      if (r.tgt >= 0 && ((flip >> r.tgt) & 1ull)) {   // X M X
+        for (int k = 0; k < 2; ++k) {
+          std::swap(r.g[k], r.g[6 + k]);
+          std::swap(r.g[2 + k], r.g[4 + k]);
+        }
+      }
+      uint64_t c = (r.ctl_mask | r.neg_mask) & flip;
+      // A diagonal gate under zero-controls expands into 2^k phase terms with inverse factors:
+      // with a zero on its diagonal (projectors) or past three zero-controls, the flips of its
+      // control bits are executed here instead.
+      const bool singular = (r.g[0] == 0.0 && r.g[1] == 0.0) || (r.g[6] == 0.0 && r.g[7] == 0.0);
+      if (plan_diag(r.g, r.tgt) && c && (singular || popc((r.neg_mask ^ c) & (r.ctl_mask | r.neg_mask)) > 3)) {
+        for (uint64_t t = c; t; t &= t - 1) {
+          const int b = __builtin_ctzll(t);
+          emit_x(b);
+          flip &= ~(1ull << b);
+        }
+        c = 0;
+      }
+      const uint64_t to_neg = r.ctl_mask & c, to_pos = r.neg_mask & c;
+      r.ctl_mask = (r.ctl_mask & ~to_neg) | to_pos;
+      r.neg_mask = (r.neg_mask & ~to_pos) | to_neg;
+      out.push_back(r);
+      oalg.push_back((*alg)[i] + carry_alg);
+      ow.push_back((*weight)[i] + carry_w);
+      carry_alg = 0;
+      carry_w = 0;
+    }
+    for (uint64_t t = flip; t; t &= t - 1) emit_x(__builtin_ctzll(t));
+    if (carry_w) {               // X pairs that cancelled with nothing after them
+      if (!ow.empty()) { ow.back() += carry_w; oalg.back() += carry_alg; }
+      else *noops += carry_w;
+    }
+    pending->swap(out);
+    alg->swap(oalg);
+    weight->swap(ow);
+  }
+
   static void mat2(const double a[8], const double b[8], double out[8]) {  // out = a * b
     for (int r = 0; r < 2; ++r)
       for (int c = 0; c < 2; ++c) {
@@ -338,7 +412,7 @@ class Planner {
       const bool diag = plan_diag(r.g, r.tgt);
       const uint64_t tb = (r.tgt >= 0) ? (1ull << r.tgt) : 0;
       const uint64_t dense_bits = diag ? 0 : tb;
-      const uint64_t diag_bits = r.ctl_mask | (diag ? tb : 0);
+      const uint64_t diag_bits = r.ctl_mask | r.neg_mask | (diag ? tb : 0);
       const bool can_pass = !(dense_bits & (blocked_all | blocked_diag)) && !(diag_bits & blocked_all);
       const bool fits = (count < (size_t)kMaxSweepOps) &&
                         (diag || ((tilemask >> r.tgt) & 1ull));
@@ -470,7 +544,7 @@ class Planner {
         if (!flags[i]) continue;
         const GateRec &r = pending[i];
         if (!plan_diag(r.g, r.tgt)) { later_targets |= 1ull << r.tgt; continue; }
-        const uint64_t bits = r.ctl_mask | (r.tgt >= 0 ? (1ull << r.tgt) : 0);
+        const uint64_t bits = r.ctl_mask | r.neg_mask | (r.tgt >= 0 ? (1ull << r.tgt) : 0);
         if (!(bits & later_targets) && (bits & future)) flags[i] = 0;
       }
     }
@@ -581,8 +655,8 @@ class Planner {
   // as physical bits, register part, outside part); bits fixed to one by the
   // enumeration are dropped (always satisfied).
   void split_mask(const SweepPlan &sp, uint64_t m, uint32_t *lane, uint64_t *lane_phys, uint32_t *reg,
-                  uint64_t *outside) const {
-    m &= ~sp.fixed_ones;
+                  uint64_t *outside, bool drop_fixed = true) const {
+    if (drop_fixed) m &= ~sp.fixed_ones;
     *lane = 0;
     *lane_phys = 0;
     *reg = 0;
@@ -680,7 +754,7 @@ class Planner {
       std::vector<int> cand;
       for (size_t i = 0; i < taken.size(); ++i) {
         const GateRec *r = taken[i];
-        if (plan_diag(r->g, r->tgt) || (r->ctl_mask & ~sp->fixed_ones)) continue;
+        if (plan_diag(r->g, r->tgt) || (r->ctl_mask & ~sp->fixed_ones) || r->neg_mask) continue;
         last = (int)i;
         if (butterflies_ && butterfly_variant(r->g) >= 0) cand.push_back((int)i);
       }
@@ -796,8 +870,10 @@ class Planner {
         size_t n_ops_after_flush = sp->ops.size() > n_ops_before ? sp->ops.size() : 0;
         SweepOp op{};
         uint32_t lane, reg; uint64_t outside, lane_phys;
+        uint32_t nlane = 0, nreg = 0; uint64_t noutside = 0, nlane_phys = 0;   // zero-controls
         split_mask(geom, r->ctl_mask, &lane, &lane_phys, &reg, &outside);
-        if (lane && lane_swapped()) {
+        if (r->neg_mask) split_mask(geom, r->neg_mask, &nlane, &nlane_phys, &nreg, &noutside, false);
+        if ((lane | nlane) && lane_swapped()) {
           // lane-bit controls are tested against the thread's ORIGINAL lane -> index-bit map
           restore_layout();
           const int wj = wave_index(geom, r->tgt);
@@ -808,9 +884,15 @@ class Planner {
           }
           n_ops_after_flush = 0;
           split_mask(geom, r->ctl_mask, &lane, &lane_phys, &reg, &outside);
+          if (r->neg_mask) split_mask(geom, r->neg_mask, &nlane, &nlane_phys, &nreg, &noutside, false);
         }
-        op.cm_thread = outside | lane_phys;   // tested against the thread's physical index
-        op.cm_reg = reg;
+        // thread controls: (index & cm_thread) == cm_thread & ~zero-controls; the zero-control
+        // mask of a dense op travels in the two header words a DIAG op uses for its groups
+        const uint64_t nthread = noutside | nlane_phys;
+        op.cm_thread = outside | lane_phys | nthread;   // tested against the thread's physical index
+        op.n_groups = (uint32_t)nthread;
+        op.group_off = (uint32_t)(nthread >> 32);
+        op.cm_reg = reg | (nreg << 8);                  // bits 0..4 must be one, bits 8..12 must be zero
         memcpy(op.g, r->g, sizeof op.g);
         if (role[gi] == 2) for (int k = 0; k < 4; ++k) cmul_acc(&op.g[2 * k], &op.g[2 * k + 1], sink_re[gi], sink_im[gi]);
         int li = lane_index(geom, r->tgt);
@@ -865,17 +947,28 @@ class Planner {
         sp->ops.push_back(op);
         continue;
       }
-      // diagonal: amp *= d0 under controls (if d0 != 1), then amp *= d1/d0 where tgt set
+      // diagonal: amp *= d0 under controls (if d0 != 1), then amp *= d1/d0 where tgt set.
+      // Zero-controls by inclusion-exclusion: [all of N are 0] = sum over S in N of (-1)^|S| [all of S are 1],
+      // i.e. factor f on (mask, none of N) = product over S of f^((-1)^|S|) on mask | S.
+      const uint64_t neg = r->neg_mask;
+      auto add_signed = [&](uint64_t mask, double fr, double fi) {
+        const double den = fr * fr + fi * fi;
+        for (uint64_t sub = neg;; sub = (sub - 1) & neg) {
+          if (popc(sub) & 1) add_pending(mask | sub, fr / den, -fi / den);
+          else add_pending(mask | sub, fr, fi);
+          if (!sub) break;
+        }
+      };
       const uint64_t bits = r->ctl_mask | (r->tgt >= 0 ? (1ull << r->tgt) : 0);
       const double d0r = r->g[0], d0i = r->g[1], d1r = r->g[6], d1i = r->g[7];
       if (r->tgt < 0) {
-        add_pending(r->ctl_mask, d0r, d0i);
+        add_signed(r->ctl_mask, d0r, d0i);
       } else if (is_one(d0r, d0i)) {
-        add_pending(bits, d1r, d1i);
+        add_signed(bits, d1r, d1i);
       } else {
-        add_pending(r->ctl_mask, d0r, d0i);
+        add_signed(r->ctl_mask, d0r, d0i);
         const double den = d0r * d0r + d0i * d0i;  // != 0: see plan_diag()
-        add_pending(bits, (d1r * d0r + d1i * d0i) / den, (d1i * d0r - d1r * d0i) / den);
+        add_signed(bits, (d1r * d0r + d1i * d0i) / den, (d1i * d0r - d1r * d0i) / den);
       }
     }
     flush_diag(&pending, ~0ull, sp, geom);

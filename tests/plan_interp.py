@@ -121,8 +121,13 @@ def run_plan(psi, sweeps, nloc, shard=0):
         continue
       # dense ops
       tgt = lanepos[tb] if kind == OP_DENSE_LANE else regpos[tb]
-      cm_reg = np.uint64(op['cm_reg'])
-      ok = in_sweep & ((slot & cm_reg) == cm_reg) & ((gidx & np.uint64(op['cm_thread'])) == np.uint64(op['cm_thread']))
+      # register controls: bits 0..4 of cm_reg must be one, bits 8..12 zero; thread controls:
+      # (index & cm_thread) == cm_thread & ~zero-controls (which travel in n_groups / group_off)
+      pos_reg, neg_reg = np.uint64(int(op['cm_reg']) & 0x1f), np.uint64((int(op['cm_reg']) >> 8) & 0x1f)
+      cmt = int(op['cm_thread'])
+      want = cmt & ~(int(op['n_groups']) | (int(op['group_off']) << 32))
+      ok = (in_sweep & ((slot & pos_reg) == pos_reg) & ((slot & neg_reg) == np.uint64(0)) &
+            ((gidx & np.uint64(cmt)) == np.uint64(want)))
       g8 = op['g']
       if flags & OPF_BFLY:
         v = (flags >> 4) & 7

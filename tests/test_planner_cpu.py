@@ -87,11 +87,34 @@ def test_commutation_rules_keep_order_where_it_matters():
   # all run in the first sweep plus seven more H; the two left-over H gates follow
   assert p['sweeps'][0]['gates'] == 11 and p['sweeps'][1]['gates'] == 2
   assert len(p['sweeps'][0]['wavepos']) == 1
-  sb = workloads.StreamBuilder()           # order must survive: X then H then X on one qubit,
-  for g in (gates.pauli_x(), gates.hadamard(), gates.pauli_x()):  # interleaved with a blocker
+  sb = workloads.StreamBuilder()           # order must survive: S then H then S on one qubit
+  for g in (gates.rx(0.3), gates.hadamard(), gates.rx(0.3)):
     sb.apply1(g, 3)
   p = _plan(n, *sb.arrays())
-  assert len(p['sweeps']) == 1 and p['sweeps'][0]['dense_ops'] == 3
+  assert len(p['sweeps']) == 1 and p['sweeps'][0]['dense_ops'] == 3 and p['sweeps'][0]['gates'] == 3
+
+
+def test_x_gates_are_pushed_through_the_circuit():
+  """Uncontrolled X gates become pending bit flips (planner.h propagate_x): X.H.X is ONE
+  conjugated gate, the X.CU.X of "controlled by |0>" (circuit.py:166-169,207-215) is ONE gate
+  with a zero-control, and a flip still pending at the end of the flush is executed there."""
+  n = 20
+  sb = workloads.StreamBuilder()
+  for g in (gates.pauli_x(), gates.hadamard(), gates.pauli_x()):
+    sb.apply1(g, 3)
+  (s,) = _plan(n, *sb.arrays())['sweeps']
+  assert s['dense_ops'] == 1 and s['gates'] == 3              # all three reference gates accounted for
+  sb = workloads.StreamBuilder()
+  sb.apply1(gates.pauli_x(), 2)
+  sb.applyc(gates.ry(0.4), 2, 9)                              # controlled by qubit 2 being |0>
+  sb.apply1(gates.pauli_x(), 2)
+  (s,) = _plan(n, *sb.arrays())['sweeps']
+  assert s['dense_ops'] == 1 and s['gates'] == 3
+  sb = workloads.StreamBuilder()
+  sb.apply1(gates.pauli_x(), 4)
+  sb.apply1(gates.hadamard(), 7)
+  (s,) = _plan(n, *sb.arrays())['sweeps']
+  assert s['dense_ops'] == 2 and s['gates'] == 2              # the X itself runs at the end
 
 
 def test_shard_bit_predicates_resolved_at_plan_time():

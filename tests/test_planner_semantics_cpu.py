@@ -1,6 +1,7 @@
 """The planner's output executed on the CPU (tests/plan_interp.py) against the oracle: random
 circuits, every plan shape the engine can be switched to, single and sharded handles.  No GPU."""
 import ctypes
+import zlib
 
 import numpy as np
 import pytest
@@ -85,7 +86,7 @@ ENVS = [{}, {'QH_WAVE_BITS': '2'}, {'QH_WAVE_BITS': '0'}, {'QH_LANE_VALU': '2'},
 def test_planned_sweeps_equal_the_oracle(oracle, monkeypatch, env):
   for k, v in env.items():
     monkeypatch.setenv(k, v)
-  rng = np.random.default_rng(hash(tuple(sorted(env.items()))) & 0xffff)
+  rng = np.random.default_rng(zlib.crc32(repr(sorted(env.items())).encode()))
   for case in range(14):
     n = int(rng.integers(10, 16))
     gshard = int(rng.integers(0, 3)) if case % 3 == 2 else 0

@@ -204,10 +204,16 @@ def gen(rb, wide=True):
   a(f's_cbranch_scc1 {L("L_bf")}')
   a('s_load_dwordx16 s[52:67], s[36:37], 0x20')  # g[8]
   # control predicate of this thread: (it & cm_thread) == cm_thread  -> s[68:69]
+  # (zero-controls: header words n_groups / group_off of a dense op hold the bits of cm_thread
+  # that must be 0; bits 8..12 of cm_reg the register bits that must be 0)
+  a('s_andn2_b32 s74, s48, s47')
+  a('s_andn2_b32 s75, s49, s50')
+  a('s_and_b32 s76, s46, 0x1f')
+  a('s_bfe_u32 s77, s46, 0x50008')
   a(f'v_and_b32 v{V_A}, s48, %6')
   a(f'v_and_b32 v{V_B}, s49, %7')
-  a(f'v_cmp_eq_u32 vcc, s48, v{V_A}')
-  a(f'v_cmp_eq_u32_e64 s[72:73], s49, v{V_B}')
+  a(f'v_cmp_eq_u32 vcc, s74, v{V_A}')
+  a(f'v_cmp_eq_u32_e64 s[72:73], s75, v{V_B}')
   a('s_nop 1')
   a('s_and_b64 s[68:69], vcc, s[72:73]')
   a('s_waitcnt lgkmcnt(0)')                   # g[8] (and the header prefetch)
@@ -263,7 +269,9 @@ def gen(rb, wide=True):
       k0 = ((h >> b) << (b + 1)) | (h & ((1 << b) - 1))
       k1 = k0 | (1 << b)
       skip = f'L_r{b}_{h}'
-      a(f's_andn2_b32 s74, s46, {k0}')      # control bits (register part) not set in k0
+      a(f's_andn2_b32 s74, s76, {k0}')      # control bits (register part) not set in k0
+      a(f's_and_b32 s75, s77, {k0}')
+      a('s_or_b32 s74, s74, s75')
       a('s_cmp_eq_u32 s74, 0')
       a(f's_cbranch_scc0 {L(skip)}')
       ar, ai, br, bi = X(k0), Y(k0), X(k1), Y(k1)
@@ -356,7 +364,9 @@ def gen(rb, wide=True):
       k0 = ((h >> b) << (b + 1)) | (h & ((1 << b) - 1))
       k1 = k0 | (1 << b)
       skip = f'L_rrc{b}_{h}'
-      a(f's_andn2_b32 s74, s46, {k0}')
+      a(f's_andn2_b32 s74, s76, {k0}')
+      a(f's_and_b32 s75, s77, {k0}')
+      a('s_or_b32 s74, s74, s75')
       a('s_cmp_eq_u32 s74, 0')
       a(f's_cbranch_scc0 {L(skip)}')
       a(MUL() + f' {ta}, {g["g0r"]}, {X(k0)}')
@@ -406,7 +416,9 @@ def gen(rb, wide=True):
 
   def comb_real_c(k, pr, pi):                    # register-bit controls: combine only the selected slots
     skip = f'L_lrc_{k}'
-    a(f's_andn2_b32 s74, s46, {k}')
+    a(f's_andn2_b32 s74, s76, {k}')
+    a(f's_and_b32 s75, s77, {k}')
+    a('s_or_b32 s74, s74, s75')
     a('s_cmp_eq_u32 s74, 0')
     a(f's_cbranch_scc0 {L(skip)}')
     comb_real(k, pr, pi)
@@ -726,7 +738,9 @@ def gen(rb, wide=True):
     for k in range(nr):
       nd = 2 * W()
       skip = f'L_lrd{tbv}_{k}'
-      a(f's_andn2_b32 s74, s46, {k}')             # register-bit controls: skip the slots they exclude
+      a(f's_andn2_b32 s74, s76, {k}')             # register-bit controls: skip the slots they exclude
+      a(f's_and_b32 s75, s77, {k}')
+      a('s_or_b32 s74, s74, s75')
       a('s_cmp_eq_u32 s74, 0')
       a(f's_cbranch_scc0 {L(skip)}')
       if len(steps) == 1:
@@ -827,7 +841,9 @@ def gen(rb, wide=True):
   a.label('L_lane_ctl')
   for k in range(nr):
     skip = f'L_l_{k}'
-    a(f's_andn2_b32 s74, s46, {k}')
+    a(f's_andn2_b32 s74, s76, {k}')
+    a(f's_and_b32 s75, s77, {k}')
+    a('s_or_b32 s74, s74, s75')
     a('s_cmp_eq_u32 s74, 0')
     a(f's_cbranch_scc0 {L(skip)}')
     shuf(k, LN_BUF[0])
