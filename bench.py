@@ -129,6 +129,9 @@ def cpu_baseline(args, ops, g8):
 
 def main():
   args = parse()
+  # every step plans its gate stream from scratch (the engine's plan cache would only save host
+  # time that is hidden behind the previous step's kernels anyway; nothing is reused across steps)
+  os.environ.setdefault('QH_PLAN_CACHE', '0')
   rank = int(os.environ.get('RANK', '0'))
   world = int(os.environ.get('WORLD_SIZE', '1'))
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
