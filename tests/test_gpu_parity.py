@@ -324,15 +324,23 @@ def test_complex64_fused_streams_vs_oracle(oracle, n, ngates, seed):
   assert np.max(np.abs(got - want)) <= 3e-5    # float32 accumulation over hundreds of gates
 
 
-def test_complex64_qft_fused_analytic():
-  n, x = 20, 0xBEEF5
+@pytest.mark.parametrize('n,bw', [(20, 64), (27, 64), (27, 128)])
+def test_qft_fused_analytic(n, bw):
+  """QFT of a basis state against the closed form, every amplitude: 20 qubits in one or two
+  sweeps; 27 qubits with super-tiles (wave bits, OP_WSWAP) in both element widths."""
+  x = 0xBEEF5 & ((1 << n) - 1)
   ops, g8 = workloads.qft_stream(range(n)).arrays()
-  with device.DeviceState(n, 64, fusion=native.QH_FUSE_SWEEP) as st:
+  with device.DeviceState(n, bw, fusion=native.QH_FUSE_SWEEP) as st:
     st.init_basis(x)
     st.run_stream(ops, g8)
     got = st.download()
-  want = workloads.qft_analytic(n, x, np.arange(1 << n))
-  assert np.max(np.abs(got - want)) < 2e-6 * 5
+    sweeps = st.stats()['sweeps']
+  assert sweeps <= 4
+  tol = (3e-5 if bw == 64 else 1e-12) * 2.0 ** (-n / 2)      # relative to the amplitude modulus 2^(-n/2)
+  for lo in range(0, 1 << n, 1 << 22):                     # closed form in slices (python-int phases)
+    idx = np.arange(lo, min(lo + (1 << 22), 1 << n), 4099 if n > 22 else 1)
+    want = workloads.qft_analytic(n, x, idx)
+    assert np.max(np.abs(got[idx] - want)) < tol
 
 
 @pytest.mark.parametrize('lane_valu', ['1', '2'])
