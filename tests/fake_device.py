@@ -84,6 +84,99 @@ class OracleDevice:
     return self.psi[index]
 
 
+class PlanDevice(OracleDevice):
+  """Like OracleDevice, but the queued gates go through the REAL planner: at every flush the
+  queue is planned by the engine library (dry handle, qh_plan_export) and the plan is executed
+  with NumPy (tests/plan_interp.py).  States below 8 qubits (no sweeps) use the oracle."""
+  planned_flushes = 0
+
+  def __init__(self, nbits, bit_width):
+    super().__init__(nbits, bit_width)
+    self.queue = []
+
+  def apply1(self, gate, index):
+    self.queue.append((None, int(index), np.asarray(gate, dtype=np.complex128).reshape(4).copy()))
+
+  def applyc(self, gate, control, target):
+    self.queue.append((int(control), int(target), np.asarray(gate, dtype=np.complex128).reshape(4).copy()))
+
+  def flush(self):
+    import ctypes
+    from qcc_amd import native
+    from tests import plan_interp
+    q, self.queue = self.queue, []
+    if not q:
+      return
+    n = self.nbits
+    in_range = all(c is None or 0 <= c < n for c, _, _ in q)
+    if n < 8 or not in_range:          # no sweeps / the reference's out-of-range control quirk: oracle semantics
+      for c, t, g in q:
+        if c is None:
+          super().apply1(g, t)
+        else:
+          super().applyc(g, c, t)
+      return
+    lib = native.load()
+    h = ctypes.c_void_p()
+    native.check(lib.qh_create_dry(n, 128, ctypes.byref(h)))
+    native.check(lib.qh_set_fusion(h, native.QH_FUSE_SWEEP))
+    dp = ctypes.POINTER(ctypes.c_double)
+    for c, t, g in q:
+      g8 = np.ascontiguousarray(g).view(np.float64)
+      if c is None:
+        native.check(lib.qh_apply1(h, t, g8.ctypes.data_as(dp)))
+      else:
+        native.check(lib.qh_applyc(h, c, t, g8.ctypes.data_as(dp)))
+    sweeps, _ = plan_interp.export_plan(h)
+    lib.qh_destroy(h)
+    work = self.psi.astype(np.complex128)
+    plan_interp.run_plan(work, sweeps, n)
+    self.psi[:] = work.astype(self.dtype)
+    PlanDevice.planned_flushes += 1
+
+  sync = flush
+
+  def download(self, offset=0, count=None, out=None):
+    self.flush()
+    return super().download(offset, count, out)
+
+  def upload(self, host, offset=0):
+    self.flush()
+    super().upload(host, offset)
+
+  def init_basis(self, index=0):
+    self.queue = []
+    super().init_basis(index)
+
+  def init_product(self, factors):
+    self.queue = []
+    super().init_product(factors)
+
+  def norm2(self):
+    self.flush()
+    return super().norm2()
+
+  def argmax(self):
+    self.flush()
+    return super().argmax()
+
+  def prob_bit(self, bit, value=1):
+    self.flush()
+    return super().prob_bit(bit, value)
+
+  def project_bit(self, bit, value):
+    self.flush()
+    super().project_bit(bit, value)
+
+  def scale(self, z):
+    self.flush()
+    super().scale(z)
+
+  def amplitude(self, index):
+    self.flush()
+    return super().amplitude(index)
+
+
 class OracleHostExecutor:
   def __init__(self):
     self.o = oracle_lib.load()

@@ -1,8 +1,9 @@
 """TEST-ONLY: run a file of the reference (its tests or algorithms) with
 ``src.lib`` resolved to qcc_amd.lib.  Container-only (needs /root/reference).
 
-usage: python tests/ref_runner.py <path/to/reference_file.py> [cpu|gpu|dropin-cpu|dropin-gpu] [args...]
+usage: python tests/ref_runner.py <path/to/reference_file.py> [cpu|plan|gpu|dropin-cpu|dropin-gpu] [args...]
   cpu: qcc_amd.lib is `src.lib`; gates run on the oracle-backed stand-in (tests/fake_device.py)
+  plan: as cpu, but every flush is planned by the engine's planner and the plan executed with NumPy
   gpu: qcc_amd.lib is `src.lib`; gates run on the MI355X
   dropin-*: the REFERENCE's own src/lib is used unmodified; only its `libxgates`
             import resolves to qcc_amd/dropin/libxgates.py (the literal boundary)
@@ -64,9 +65,10 @@ def main():
   from qcc_amd.lib import backend, tensor
   if os.environ.get('QCC_TENSOR_WIDTH'):
     tensor.set_tensor_width(int(os.environ['QCC_TENSOR_WIDTH']))
-  if mode == 'cpu':
+  if mode in ('cpu', 'plan'):
     from tests import fake_device
-    backend.set_device_factory(fake_device.OracleDevice)
+    # plan: gates go through the engine's planner; the plan is executed with NumPy (no GPU)
+    backend.set_device_factory(fake_device.PlanDevice if mode == 'plan' else fake_device.OracleDevice)
     backend.set_host_executor(fake_device.OracleHostExecutor())
   # algorithms import helpers as `from src.lib import ...` (ours) and each other as
   # `from src import x`: expose the reference's src/ directory for the latter only.

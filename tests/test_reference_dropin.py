@@ -54,5 +54,14 @@ def test_reference_algorithms_on_literal_libxgates_dropin(name):
   _run(os.path.join(REF, name + '.py'), 'dropin-cpu')
 
 
+@pytest.mark.parametrize('name', ['circuit_test', 'measure_test', 'arith_quantum', 'supremacy', 'phase_estimation',
+                                  'inversion_test', 'qram'])
+def test_reference_code_through_the_planner(name):
+  """The reference's own tests / algorithms with every flush planned by the engine's sweep planner
+  (dry handle) and the plan executed with NumPy: the planner under the reference's real call patterns."""
+  path = os.path.join(REF, 'lib', name + '.py') if name in REF_TESTS else os.path.join(REF, name + '.py')
+  _run(path, 'plan', env={'QCC_TENSOR_WIDTH': '128'})
+
+
 def test_complex128_width_on_api_mirror():
   _run(os.path.join(REF, 'lib', 'circuit_test.py'), 'cpu', env={'QCC_TENSOR_WIDTH': '128'})
