@@ -56,7 +56,17 @@ __global__ __launch_bounds__(256) void k_geom(v2d *__restrict__ p, uint64_t ntil
 int main(int argc, char **argv) {
   int nb = argc > 1 ? atoi(argv[1]) : 30;
   uint64_t n = 1ull << nb; size_t bytes = n * 16;
-  v2d *p; CK(hipMalloc(&p, bytes)); CK(hipMemset(p, 0, bytes));
+  v2d *p;
+  if (getenv("GEOM_ALIGN")) {   // over-allocate and align the base to the state size
+    char *raw; CK(hipMalloc(&raw, 2 * bytes));
+    uintptr_t a = ((uintptr_t)raw + bytes - 1) / bytes * bytes;
+    p = (v2d *)a;
+    printf("raw %p aligned %p\n", (void *)raw, (void *)p);
+  } else {
+    CK(hipMalloc(&p, bytes));
+    printf("base %p\n", (void *)p);
+  }
+  CK(hipMemset(p, 0, bytes));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   uint64_t ntiles = n >> 11;
   for (int a = 2; a < argc; ++a) {
