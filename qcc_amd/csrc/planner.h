@@ -236,6 +236,7 @@ class Planner {
   int max_wave_ = std::max(0, std::min(kMaxWaveBits, env_int("QH_WAVE_BITS", 1)));
   bool propagate_x_ = env_flag("QH_PROPAGATE_X", true);   // see propagate_x
   bool store_swapped_ = env_flag("QH_STORE_SWAPPED", true);
+  bool lanes_by_count_ = env_flag("QH_LANES_BY_COUNT", true);
   bool lanes_high_ = env_flag("QH_LANES_HIGH", true);
   int min_table_terms_ = env_int("QH_MIN_TABLE_TERMS", 2);
   int lane_valu_ = env_int("QH_LANE_VALU", 1);          // 0 never, 1 by cost model (choose_lane_paths), 2 always (tests)
@@ -529,7 +530,7 @@ class Planner {
     }
     assign_bits(sel, &lanehi, &regs, &waves);
     uint64_t regmask = mask_of(regs);
-    const uint64_t lanemask = always | mask_of(lanehi);
+    uint64_t lanemask = always | mask_of(lanehi);
     std::vector<uint8_t> flags(pending.size(), 0);
     pass(pending, lanemask | regmask | mask_of(waves), pending.size(), &flags);
     // A diagonal gate that no dense op of THIS sweep waits for, but a dense gate of a later
@@ -574,6 +575,36 @@ class Planner {
       }
       sp.gates = weight_[0];
       sp.alg_bytes = alg[0];
+    }
+    // Op-heavy sweeps (many dense gates per tile: supremacy layers) are bound by instruction
+    // issue, and a lane-bit gate costs 2-4x a register-bit gate: among the bits of a split-lane
+    // tile the ones with the FEWEST dense gates take the lane roles.  (The tile mask, hence the
+    // set of gates taken, does not change.)
+    if (lanes_by_count_) {
+      std::vector<int> cnt(64, 0);
+      int ndense = 0;
+      for (const GateRec *r : taken)
+        if (!plan_diag(r->g, r->tgt) && r->tgt >= 0) { cnt[r->tgt]++; ndense++; }
+      if (ndense >= 16) {
+        for (int iter = 0; iter < kLaneHi; ++iter) {
+          int bl = -1, br = -1, gain = 0;
+          for (size_t i = 0; i < lanehi.size(); ++i) {
+            if (lanehi[i] < kLaneBits) continue;            // 3,4,5: fixed by contiguity
+            for (size_t j = 0; j < regs.size(); ++j)
+              if (regs[j] <= kMaxLaneHiBit && cnt[lanehi[i]] - cnt[regs[j]] > gain) {
+                gain = cnt[lanehi[i]] - cnt[regs[j]];
+                bl = (int)i;
+                br = (int)j;
+              }
+          }
+          if (gain < 2) break;
+          std::swap(lanehi[bl], regs[br]);
+        }
+        std::sort(lanehi.begin(), lanehi.end());
+        std::sort(regs.begin(), regs.end());
+        regmask = mask_of(regs);
+        lanemask = always | mask_of(lanehi);
+      }
     }
     // drop register bits that ended up unused (a later candidate made them moot)
     {
