@@ -156,9 +156,9 @@ int qh_timer_end(qh_handle h, float *milliseconds);
 int qh_plan_json(qh_handle h, char *buf, uint64_t cap, uint64_t *needed);
 
 /* The same plan in binary form, complete (ops, phase groups, tables): 3 x u64 (magic
- * 0x51485031, sweeps, gates dropped as no-ops), then per sweep 24 x i64 (rb, regpos[5],
+ * 0x51485031, sweeps, gates dropped as no-ops), then per sweep 26 x i64 (rb, regpos[5],
  * regpos_store[5], lanehi[3], nwave, wavepos[2], fixed_ones, ntiles, #ops, #groups, #oterms,
- * #table doubles, #lane tables) followed by the SweepOp / DGroup / OTerm / table arrays of
+ * #table doubles, #lane tables, lane_low, 0) followed by the SweepOp / DGroup / OTerm / table arrays of
  * qcc_amd/csrc/planner.h, each padded to 8 bytes.  For tools and tests that check a plan
  * without a GPU (tests/plan_interp.py executes it with NumPy).                 */
 int qh_plan_export(qh_handle h, void *buf, uint64_t cap, uint64_t *needed);

@@ -844,7 +844,7 @@ int qh_timer_end(qh_handle h, float *ms) {
 int qh_plan_json(qh_handle h, char *buf, uint64_t cap, uint64_t *needed) {
   if (!h) return fail(QH_ERR_ARG, "null");
   std::string s = qh::plan_to_json(h->queue, h->nloc, h->shard, h->bw, qh::sweep_max_rb(),
-                                   qh::sweep_split_lanes() && h->bw == 128);
+                                   qh::sweep_split_lanes());
   if (needed) *needed = s.size() + 1;
   if (buf && cap) {
     const uint64_t n = std::min<uint64_t>(cap - 1, s.size());
@@ -858,7 +858,7 @@ int qh_plan_export(qh_handle h, void *buf, uint64_t cap, uint64_t *needed) {
   if (!h) return fail(QH_ERR_ARG, "null");
   if (!qh::sweep_supported(h->nloc, h->bw)) return fail(QH_ERR_ARG, "state too small for sweeps");
   qh::PlanResult pr = qh::plan_best(h->queue, h->nloc, h->shard, h->bw, qh::sweep_max_rb(),
-                                    qh::sweep_split_lanes() && h->bw == 128);
+                                    qh::sweep_split_lanes());
   std::vector<uint64_t> out;
   auto put_bytes = [&](const void *p, size_t n) {
     const size_t w = (n + 7) / 8, at = out.size();
@@ -869,7 +869,7 @@ int qh_plan_export(qh_handle h, void *buf, uint64_t cap, uint64_t *needed) {
   out.push_back(pr.sweeps.size());
   out.push_back(pr.noop_gates);
   for (auto &sp : pr.sweeps) {
-    int64_t hdr[24] = {0};
+    int64_t hdr[26] = {0};
     int k = 0;
     hdr[k++] = sp.rb;
     for (int i = 0; i < 5; ++i) hdr[k++] = sp.regpos[i];
@@ -884,6 +884,7 @@ int qh_plan_export(qh_handle h, void *buf, uint64_t cap, uint64_t *needed) {
     hdr[k++] = (int64_t)sp.oterms.size();
     hdr[k++] = (int64_t)sp.tables.size();
     hdr[k++] = sp.n_ltab;
+    hdr[k++] = sp.lane_low;
     put_bytes(hdr, sizeof hdr);
     put_bytes(sp.ops.data(), sp.ops.size() * sizeof(qh::SweepOp));
     put_bytes(sp.groups.data(), sp.groups.size() * sizeof(qh::DGroup));

@@ -47,7 +47,8 @@ inline bool plan_diag(const double g[8], int tgt) {
 }
 
 constexpr int kLaneBits = 6;   // wavefront = 64 lanes
-constexpr int kLaneLow = 3;    // lane bits 0..2 are ALWAYS index bits 0..2 (one 128-byte line per 8 lanes)
+constexpr int kLaneLow = 3;    // complex128: lane bits 0..2 are ALWAYS index bits 0..2 (8 x 16 B = one 128-byte line);
+                               // complex64 uses 4 (16 x 8 B): SweepPlan::lane_low
 constexpr int kLaneHi = 3;     // lane bits 3..5 sit on index bits 3,4,5 -- or on any three bits <= kMaxLaneHiBit
 constexpr int kMaxLaneHiBit = 27;  // per-lane byte offset must fit the 32-bit voffset of global_load
 constexpr int kMaxRegBits = 5; // 32 amplitudes (128 VGPRs of data) per lane
@@ -129,7 +130,13 @@ struct SweepPlan {
   int rb = 0;                      // register bits used by the kernel instance
   int regpos[kMaxRegBits] = {0};   // ascending physical positions
   int regpos_store[kMaxRegBits] = {0};  // register bits when the tile is stored (OP_WSWAPs are not undone)
-  int lanehi[kLaneHi] = {3, 4, 5}; // ascending positions of lane bits 3,4,5 ({3,4,5} = contiguous 1-KiB runs)
+  int lane_low = kLaneLow;         // lane bits below this are the index bits of the same number
+  int lanehi[kLaneHi] = {3, 4, 5}; // ascending positions of the 6 - lane_low movable lane bits ({lane_low..5} = contiguous runs)
+  int nlanehi() const { return kLaneBits - lane_low; }
+  bool contiguous() const {
+    for (int k = 0; k < nlanehi(); ++k) if (lanehi[k] != lane_low + k) return false;
+    return true;
+  }
   int nwave = 0;                   // wave bits: the 2^nwave waves of a workgroup hold the tiles differing in
   int wavepos[kMaxWaveBits] = {0}; // these index bits; a gate on one runs after OP_WSWAP moved it into registers
   uint64_t fixed_ones = 0;         // local bits fixed to 1 in the tile enumeration
@@ -168,6 +175,8 @@ class Planner {
   Planner(int nloc, uint64_t shard, int bw, int max_rb, bool split_lanes = true, int wave_bits = -1)
       : nloc_(nloc), shard_(shard), amp_bytes_(bw == 128 ? 16 : 8), split_lanes_(split_lanes) {
     rb_cap_ = std::min({max_rb, kMaxRegBits, nloc - kLaneBits});
+    lane_low_ = bw == 128 ? 3 : 4;   // 128-byte lines: 8 complex128 or 16 complex64 amplitudes
+    lane_hi_ = kLaneBits - lane_low_;
     if (wave_bits >= 0) max_wave_ = std::min(wave_bits, kMaxWaveBits);
   }
 
@@ -229,6 +238,7 @@ class Planner {
   uint64_t shard_;
   uint64_t amp_bytes_;
   int rb_cap_;
+  int lane_low_ = kLaneLow, lane_hi_ = kLaneHi;
   bool split_lanes_;   // allow lane bits 3..5 to sit on arbitrary index bits (8 free tile bits)
   bool butterflies_ = env_flag("QH_BFLY", true);        // unit-entry butterfly ops (emit_ops_with)
   size_t dense_weight_ = env_int("QH_PLAN_DENSE_W", 1);  // score of a dense gate when choosing tile bits (diagonal = 1)
@@ -443,14 +453,14 @@ class Planner {
   bool assign_bits(const std::vector<int> &sel, std::vector<int> *lanehi, std::vector<int> *regs,
                    std::vector<int> *waves) const {
     std::vector<int> low, other;
-    for (int b : sel) ((b >= kLaneLow && b < kLaneBits) ? low : other).push_back(b);
+    for (int b : sel) ((b >= lane_low_ && b < kLaneBits) ? low : other).push_back(b);
     std::sort(low.begin(), low.end());
     std::sort(other.begin(), other.end());
     const int extra = std::max<int>(0, (int)other.size() - rb_cap_);
     const int nw = std::min(extra, max_wave_);
     const int need_move = extra - nw;
     if (need_move > 0 && !split_lanes_) return false;
-    if ((int)low.size() + need_move > kLaneHi) return false;
+    if ((int)low.size() + need_move > lane_hi_) return false;
     if (need_move > 0) {
       // split-lane tile: the LOWEST bits go to the wave id, the highest to the registers
       // (tools/geom_scan_waves.py, targets 13..22: 7.9 ms vs 8.8 ms the other way round)
@@ -481,10 +491,10 @@ class Planner {
       lanehi->insert(lanehi->end(), other.begin(), other.begin() + need_move);
       regs->assign(other.begin() + need_move, other.end());
     }
-    for (int b = kLaneLow; b < kLaneBits && (int)lanehi->size() < kLaneHi; ++b)   // spare slots: 3,4,5
+    for (int b = lane_low_; b < kLaneBits && (int)lanehi->size() < lane_hi_; ++b)   // spare slots: the contiguous positions
       if (std::find(lanehi->begin(), lanehi->end(), b) == lanehi->end()) lanehi->push_back(b);
     std::sort(lanehi->begin(), lanehi->end());
-    return (int)lanehi->size() == kLaneHi;
+    return (int)lanehi->size() == lane_hi_;
   }
 
   static uint64_t mask_of(const std::vector<int> &bits) {
@@ -503,17 +513,17 @@ class Planner {
                         std::vector<uint32_t> *rest_w) {
     SweepPlan sp;
     const size_t window = std::min<size_t>(pending.size(), 4096);
-    const uint64_t always = (1ull << kLaneLow) - 1;
+    const uint64_t always = (1ull << lane_low_) - 1;
     std::vector<int> cand;       // dense target bits above bit 2, in order of first use
     for (size_t i = 0; i < window; ++i) {
       const GateRec &r = pending[i];
-      if (!plan_diag(r.g, r.tgt) && r.tgt >= kLaneLow &&
+      if (!plan_diag(r.g, r.tgt) && r.tgt >= lane_low_ &&
           std::find(cand.begin(), cand.end(), r.tgt) == cand.end())
         cand.push_back(r.tgt);
     }
     std::vector<int> sel, lanehi, regs, waves;
     size_t best_total = pass(pending, always, window, nullptr);
-    while ((int)sel.size() < kLaneHi + rb_cap_ + max_wave_) {
+    while ((int)sel.size() < lane_hi_ + rb_cap_ + max_wave_) {
       int best_bit = -1;
       size_t best = best_total;
       for (int c : cand) {
@@ -586,7 +596,7 @@ class Planner {
       for (const GateRec *r : taken)
         if (!plan_diag(r->g, r->tgt) && r->tgt >= 0) { cnt[r->tgt]++; ndense++; }
       if (ndense >= 16) {
-        for (int iter = 0; iter < kLaneHi; ++iter) {
+        for (int iter = 0; iter < lane_hi_; ++iter) {
           int bl = -1, br = -1, gain = 0;
           for (size_t i = 0; i < lanehi.size(); ++i) {
             if (lanehi[i] < kLaneBits) continue;            // 3,4,5: fixed by contiguity
@@ -639,24 +649,25 @@ class Planner {
     int rb = std::max<int>((int)regs.size(), std::min(rb_cap_, any_dense ? rb_cap_ : 3));
     const int nwv = (int)waves.size();
     while (popc(common) > 0 && nloc_ - kLaneBits - popc(common) - nwv < rb) common &= common - 1;
-    while (popc(common) + rb + kLaneHi + nwv > kMaxInsertBits) common &= common - 1;  // the rest stay per-op controls
+    while (popc(common) + rb + lane_hi_ + nwv > kMaxInsertBits) common &= common - 1;  // the rest stay per-op controls
     rb = std::min(rb, nloc_ - kLaneBits - popc(common) - nwv);
     sp.fixed_ones = common;
     // pad the register tile with free bits: 10..13 first (a tile whose spare register
     // bits sit there streams ~10% faster than with bits 6..9 next to contiguous lanes
     // or with bits >= 18: tools/geom_scan.py), then the lowest free ones
     auto pad = [&](int p) {
-      if ((int)regs.size() < rb && p >= kLaneLow && p < nloc_ && !((regmask | common | lanemask | wavemask) >> p & 1ull)) {
+      if ((int)regs.size() < rb && p >= lane_low_ && p < nloc_ && !((regmask | common | lanemask | wavemask) >> p & 1ull)) {
         regs.push_back(p);
         regmask |= 1ull << p;
       }
     };
     for (int p = 10; p < 14; ++p) pad(p);
-    for (int p = kLaneLow; p < nloc_; ++p) pad(p);
+    for (int p = lane_low_; p < nloc_; ++p) pad(p);
     std::sort(regs.begin(), regs.end());
     sp.rb = (int)regs.size();
     for (int k = 0; k < sp.rb; ++k) sp.regpos[k] = regs[k];
-    for (int k = 0; k < kLaneHi; ++k) sp.lanehi[k] = lanehi[k];
+    sp.lane_low = lane_low_;
+    for (int k = 0; k < kLaneHi; ++k) sp.lanehi[k] = k < lane_hi_ ? lanehi[k] : -1;
     sp.nwave = nwv;
     for (int k = 0; k < nwv; ++k) sp.wavepos[k] = waves[k];
     sp.ntiles = 1ull << (nloc_ - kLaneBits - sp.rb - popc(common));
@@ -677,8 +688,8 @@ class Planner {
 
   // lane-bit index (0..5) of a physical index bit, -1 if it is not a lane bit of this tile
   static int lane_index(const SweepPlan &sp, int pos) {
-    if (pos >= 0 && pos < kLaneLow) return pos;
-    for (int k = 0; k < kLaneHi; ++k) if (sp.lanehi[k] == pos) return kLaneLow + k;
+    if (pos >= 0 && pos < sp.lane_low) return pos;
+    for (int k = 0; k < sp.nlanehi(); ++k) if (sp.lanehi[k] == pos) return sp.lane_low + k;
     return -1;
   }
 
@@ -819,6 +830,7 @@ class Planner {
     geom.fixed_ones = sp->fixed_ones;
     memcpy(geom.regpos, sp->regpos, sizeof geom.regpos);
     memcpy(geom.lanehi, sp->lanehi, sizeof geom.lanehi);
+    geom.lane_low = sp->lane_low;
     geom.nwave = sp->nwave;
     memcpy(geom.wavepos, sp->wavepos, sizeof geom.wavepos);
     // layout exchanges so far (undone in reverse): kind (0 lane / 1 wave), its bit index, register bit
@@ -830,7 +842,7 @@ class Planner {
       op.tb = (uint32_t)li;
       op.cm_reg = (uint32_t)r;
       sp->ops.push_back(op);
-      std::swap(geom.lanehi[li - kLaneLow], geom.regpos[r]);
+      std::swap(geom.lanehi[li - geom.lane_low], geom.regpos[r]);
     };
     auto wswap = [&](int wi, int r) {
       SweepOp op{};
@@ -1008,8 +1020,7 @@ class Planner {
     // offsets, base corrected by the moved index bits) -- one LDS exchange less per wave bit.
     // (only for tiles with contiguous lanes: with split lanes the exchanged layout is the
     // slower store geometry -- 7.1 vs 6.75 ms on sweep 2 of the QFT -- and undoing wins)
-    const bool contiguous = sp->lanehi[0] == 3 && sp->lanehi[1] == 4 && sp->lanehi[2] == 5;
-    if (store_swapped_ && contiguous) {
+    if (store_swapped_ && sp->contiguous()) {
       while (!swaps.empty() && !swaps.back().wave) { lswap(swaps.back().idx, swaps.back().r); swaps.pop_back(); }
     } else {
       restore_layout();
@@ -1063,7 +1074,7 @@ class Planner {
     // load per 8 index bits at run time); the rest stay loop terms
     auto attach_outside = [&](DGroup &g, PGroup &pg) {
       std::vector<OTerm> loop_terms = pg.multi;
-      for (int shift = kLaneLow; shift < 64 && !pg.single.empty(); shift += 8) {
+      for (int shift = sp->lane_low; shift < 64 && !pg.single.empty(); shift += 8) {
         const uint64_t cmask = (shift + 8 >= 64) ? (~0ull << shift) : (((1ull << 8) - 1) << shift);
         std::vector<OTerm> in;
         for (auto &o : pg.single) if (o.mask & cmask) in.push_back(o);
@@ -1147,7 +1158,7 @@ class Planner {
 inline bool plan_has_far_tile(const PlanResult &pr) {
   for (const SweepPlan &sp : pr.sweeps) {
     int far = 0;
-    for (int k = 0; k < kLaneHi; ++k) far += sp.lanehi[k] >= 25;
+    for (int k = 0; k < sp.nlanehi(); ++k) far += sp.lanehi[k] >= 25;
     for (int k = 0; k < sp.rb; ++k) far += sp.regpos[k] >= 25;
     if (far >= 8) return true;
   }
@@ -1191,7 +1202,7 @@ inline std::string plan_to_json(const std::vector<GateRec> &queue, int nloc, uin
     std::string rp = "[";
     for (int k = 0; k < sp.rb; ++k) rp += (k ? "," : "") + std::to_string(sp.regpos[k]);
     rp += "],\"lanehi\":[";
-    for (int k = 0; k < kLaneHi; ++k) rp += (k ? "," : "") + std::to_string(sp.lanehi[k]);
+    for (int k = 0; k < sp.nlanehi(); ++k) rp += (k ? "," : "") + std::to_string(sp.lanehi[k]);
     rp += "],\"wavepos\":[";
     for (int k = 0; k < sp.nwave; ++k) rp += (k ? "," : "") + std::to_string(sp.wavepos[k]);
     rp += "]";

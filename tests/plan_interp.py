@@ -41,11 +41,12 @@ def export_plan(handle):
   pos = 24
   sweeps = []
   for _ in range(nsweeps):
-    hdr = raw[pos:pos + 192].view('<i8')
-    pos += 192
+    hdr = raw[pos:pos + 208].view('<i8')
+    pos += 208
     sp = {'rb': int(hdr[0]), 'regpos': [int(x) for x in hdr[1:6]], 'regpos_store': [int(x) for x in hdr[6:11]],
           'lanehi': [int(x) for x in hdr[11:14]], 'nwave': int(hdr[14]), 'wavepos': [int(x) for x in hdr[15:17]],
-          'fixed_ones': int(hdr[17]) & (2 ** 64 - 1), 'ntiles': int(hdr[18]), 'n_ltab': int(hdr[23])}
+          'fixed_ones': int(hdr[17]) & (2 ** 64 - 1), 'ntiles': int(hdr[18]), 'n_ltab': int(hdr[23]),
+          'lane_low': int(hdr[24])}
     for name, dt, count in (('ops', OP_DT, int(hdr[19])), ('groups', GROUP_DT, int(hdr[20])),
                             ('oterms', OTERM_DT, int(hdr[21])), ('tables', np.dtype('<f8'), int(hdr[22]))):
       nbytes = count * dt.itemsize
@@ -68,7 +69,8 @@ def run_plan(psi, sweeps, nloc, shard=0):
   for sp in sweeps:
     rb = sp['rb']
     regpos = list(sp['regpos'][:rb])
-    lanepos = [0, 1, 2] + list(sp['lanehi'])
+    low = sp['lane_low']
+    lanepos = list(range(low)) + list(sp['lanehi'][:6 - low])
     wavepos = list(sp['wavepos'][:sp['nwave']])
     fixed = np.uint64(sp['fixed_ones'])
     in_sweep = (idx & fixed) == fixed
@@ -151,7 +153,7 @@ def run_plan(psi, sweeps, nloc, shard=0):
       psi[i0] = (m[0, 0] * a + m[0, 1] * b).astype(psi.dtype)
       psi[i1] = (m[1, 0] * a + m[1, 1] * b).astype(psi.dtype)
     # the tile is stored with `regpos_store`; lane exchanges must have been undone
-    assert lanepos == [0, 1, 2] + list(sp['lanehi']), 'lane layout not restored before the store'
+    assert lanepos == list(range(low)) + list(sp['lanehi'][:6 - low]), 'lane layout not restored before the store'
     assert regpos == list(sp['regpos_store'][:rb]), 'store layout disagrees with the exported one'
     assert sorted(regpos + wavepos) == sorted(list(sp['regpos'][:rb]) + list(sp['wavepos'][:sp['nwave']]))
   return psi

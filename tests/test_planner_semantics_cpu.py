@@ -60,10 +60,10 @@ def _oracle_apply(oracle, psi, n, stream):
       psi[mask] = tmp[mask]
 
 
-def _planned(n, nloc, shard, stream):
+def _planned(n, nloc, shard, stream, bw=128):
   lib = native.load()
   h = ctypes.c_void_p()
-  native.check(lib.qh_create_dry(nloc, 128, ctypes.byref(h)))
+  native.check(lib.qh_create_dry(nloc, bw, ctypes.byref(h)))
   if nloc != n:
     native.check(lib.qh_set_shard(h, n, shard))
   native.check(lib.qh_set_fusion(h, native.QH_FUSE_SWEEP))
@@ -104,6 +104,27 @@ def test_planned_sweeps_equal_the_oracle(oracle, monkeypatch, env):
       got[shard << nloc: (shard + 1) << nloc] = part
     err = float(np.max(np.abs(got - want)))
     assert err < 1e-11, (env, case, n, gshard, err)
+
+
+@pytest.mark.parametrize('env', [{}, {'QH_WAVE_BITS': '2'}, {'QH_LANE_VALU': '2'}], ids=['default', 'WAVE_BITS=2', 'LANE_VALU=2'])
+def test_planned_sweeps_complex64_geometry(oracle, monkeypatch, env):
+  """complex64 tiles have FOUR fixed low lane bits (16 x 8 B = one line) and two movable ones: the
+  plan for a 64-bit-wide handle, executed in double precision, must equal the oracle too."""
+  for k, v in env.items():
+    monkeypatch.setenv(k, v)
+  rng = np.random.default_rng(zlib.crc32(repr(sorted(env.items())).encode()) + 64)
+  for case in range(10):
+    n = int(rng.integers(10, 16))
+    stream = _stream(rng, n, int(rng.integers(20, 220)))
+    psi = rng.standard_normal(1 << n) + 1j * rng.standard_normal(1 << n)
+    psi = (psi / np.linalg.norm(psi)).astype(np.complex128)
+    want = psi.copy()
+    _oracle_apply(oracle, want, n, stream)
+    got = psi.copy()
+    sweeps = _planned(n, n, 0, stream, bw=64)
+    assert all(sp['lane_low'] == 4 for sp in sweeps)
+    plan_interp.run_plan(got, sweeps, n)
+    assert float(np.max(np.abs(got - want))) < 1e-11, (env, case, n)
 
 
 def test_reference_workload_plans_equal_the_oracle(oracle):
