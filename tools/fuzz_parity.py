@@ -44,6 +44,8 @@ def pools(rng):
 def one_case(rng, case):
   n = int(rng.integers(7, 22)) if rng.random() < 0.9 else int(rng.integers(22, 25))
   bw = 128 if rng.random() < 0.8 else 64
+  if os.environ.get('FUZZ_BW'):
+    bw = int(os.environ['FUZZ_BW'])
   ngates = int(rng.integers(20, 500)) if n < 22 else int(rng.integers(20, 120))
   gsh = int(rng.integers(0, 3)) if n >= 10 and rng.random() < 0.3 else 0   # shard bits (top qubits 0..gsh-1)
   w = rng.dirichlet([1, 1, 1, 1])              # butterfly / diagonal / real / general mix

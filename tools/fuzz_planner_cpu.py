@@ -39,7 +39,7 @@ while time.time() - t0 < budget:
   try:
     for shard in range(1 << gshard):
       part = psi[shard << nloc: (shard + 1) << nloc].copy()
-      plan_interp.run_plan(part, _planned(n, nloc, shard, stream), nloc, shard)
+      plan_interp.run_plan(part, _planned(n, nloc, shard, stream, bw=int(os.environ.get('FUZZ_BW', 128 if cases % 3 else 64))), nloc, shard)
       got[shard << nloc: (shard + 1) << nloc] = part
     err = float(np.max(np.abs(got - want)))
   except AssertionError as e:
