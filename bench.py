@@ -7,8 +7,12 @@ full 465-gate stream of qc.qft on 30 qubits (src/lib/circuit.py:320-328), every
 gate submitted through the C-ABI (qh_apply1 / qh_applyc), state resident in HBM.
 
   python bench.py --gpus N --steps K --warmup W
-  (N>1: launched by torch.distributed.run, one rank per GPU; the state is
-   sharded by its top log2(N) index bits, weak scaling: 2^30 amplitudes/GPU.)
+  N = 1: BASELINE config 2, the 30-qubit QFT (the headline and the roofline kernel); the line also
+         carries `ladder_base` = the 33-qubit QFT on the same GPU, the N=1 point of config 5's ladder.
+  N > 1: launched by torch.distributed.run, one rank per GPU; BASELINE config 5's ladder --
+         34 / 35 / 36 qubits on 2 / 4 / 8 GPUs, the state sharded by its top log2(N) index bits,
+         2^33 amplitudes = 128 GiB per GPU (weak scaling).  --qubits overrides.
+  `value` is in units of 2^30-amplitude gate applications in every case, so the lines compare.
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").
 """
@@ -33,7 +37,9 @@ def parse():
   ap.add_argument('--gpus', type=int, default=1)
   ap.add_argument('--steps', type=int, default=5)
   ap.add_argument('--warmup', type=int, default=1)
-  ap.add_argument('--qubits', type=int, default=0, help='default 30 + log2(gpus)')
+  ap.add_argument('--qubits', type=int, default=0,
+                  help='default: 30 on one GPU (BASELINE config 2); 33 + log2(gpus) on several (config 5 ladder)')
+  ap.add_argument('--no-ladder-base', action='store_true', help='N=1: skip the extra 33-qubit measurement')
   ap.add_argument('--fusion', type=int, default=-1, help='0 per-gate kernels, 1 fused sweeps (default)')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--sharded', action='store_true', help='use the multi-GPU layer even with one rank (smoke)')
@@ -127,6 +133,59 @@ def cpu_baseline(args, ops, g8):
   }
 
 
+def timed_steps(eng, ops, g8, steps, warmup, dist):
+  """W untimed steps, then exactly K steps bracketed by barrier + device sync on both sides.
+  Returns (wall seconds: max over ranks, HIP-event ms on the engine's stream, engine stats)."""
+  for _ in range(warmup):
+    eng.run_stream(ops, g8)
+    eng.flush()  # a step is one observable qc.qft(): never fuse across steps
+  eng.sync()
+  eng.reset_stats()
+  if dist is not None:
+    import torch
+    torch.cuda.synchronize()
+    dist.barrier()
+  t0 = time.perf_counter()
+  eng.timer_begin()
+  for _ in range(steps):
+    eng.run_stream(ops, g8)
+    eng.flush()
+  ev_ms = eng.timer_end()  # flushes + waits for the stream
+  eng.sync()
+  if dist is not None:
+    import torch
+    torch.cuda.synchronize()
+    dist.barrier()
+  wall = time.perf_counter() - t0
+  if dist is not None:
+    import torch
+    t = torch.tensor([wall], dtype=torch.float64, device=eng._red_device())
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall = float(t.item())
+  return wall, ev_ms, eng.stats()
+
+
+def ladder_base(device_index, fusion, steps=3):
+  """The N=1 point of BASELINE config 5's ladder (33/34/35/36 qubits on 1/2/4/8 GPUs, 2^33
+  amplitudes = 128 GiB per GPU): a 33-qubit QFT on this GPU, outside the headline's timed region."""
+  from qcc_amd import device, native, workloads
+  n = 33
+  try:
+    eng = device.DeviceState(n, 128, device=device_index, fusion=fusion)
+  except native.QhError as e:
+    return {'qubits': n, 'error': str(e)}
+  with eng:
+    ops, g8 = workloads.qft_stream(range(n)).arrays()
+    eng.init_basis(0x12CB9A5E3 & ((1 << n) - 1))
+    wall, ev_ms, st = timed_steps(eng, ops, g8, steps, 1, None)
+    norm2 = eng.norm2()
+  units = 2 ** (n - 30)
+  return {'qubits': n, 'gates_per_step': len(ops), 'steps': steps, 'ms_per_step': wall / steps * 1e3,
+          'value': len(ops) * steps * units / wall, 'unit': 'gate-applies/s (2^30-amplitude units)',
+          'kernels_per_step': st['kernels_launched'] / steps,
+          'hbm_GBps_swept': st['bytes_swept'] / (ev_ms * 1e-3) / 1e9, 'norm2': norm2}
+
+
 def main():
   args = parse()
   # every step plans its gate stream from scratch (the engine's plan cache would only save host
@@ -147,7 +206,7 @@ def main():
     local_rank %= native.device_count()
   gbits = int(math.log2(world))
   assert 1 << gbits == world, 'number of GPUs must be a power of two'
-  n = args.qubits or (30 + gbits)
+  n = args.qubits or (30 if world == 1 else 33 + gbits)
   nloc = n - gbits
   args.qubits_shard = nloc
   fusion = args.fusion if args.fusion >= 0 else native.QH_FUSE_SWEEP
@@ -162,35 +221,9 @@ def main():
 
   ops, g8 = workloads.qft_stream(range(n)).arrays()
   ngates = len(ops)
-  x = 0x2CB9A5E3 & ((1 << n) - 1)
+  x = 0x12CB9A5E3 & ((1 << n) - 1)
   eng.init_basis(x)
-  for _ in range(args.warmup):
-    eng.run_stream(ops, g8)
-    eng.flush()  # a step is one observable qc.qft(): never fuse across steps
-  eng.sync()
-  eng.reset_stats()
-  if dist is not None:
-    import torch
-    torch.cuda.synchronize()
-    dist.barrier()
-  t0 = time.perf_counter()
-  eng.timer_begin()
-  for _ in range(args.steps):
-    eng.run_stream(ops, g8)
-    eng.flush()
-  ev_ms = eng.timer_end()  # flushes + waits for the stream
-  eng.sync()
-  if dist is not None:
-    import torch
-    torch.cuda.synchronize()
-    dist.barrier()
-  wall = time.perf_counter() - t0
-  if dist is not None:
-    import torch
-    t = torch.tensor([wall], dtype=torch.float64, device=eng._red_device())
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    wall = float(t.item())
-  stats = eng.stats()
+  wall, ev_ms, stats = timed_steps(eng, ops, g8, args.steps, args.warmup, dist)
 
   # parity guard inside the bench: closed form on sampled amplitudes after the
   # first full QFT is checked in tests; here we check the norm (cheap, device-side)
@@ -199,8 +232,8 @@ def main():
   out = None
   if rank == 0:
     steps = args.steps
-    shard_units = world  # one gate on a 2^(30+g) state = 2^g shard-gate-applies of 2^30
-    value = ngates * steps * shard_units / wall
+    units = world * 2.0 ** (nloc - 30)  # one gate on a 2^n state = 2^(n-30) gate applications of 2^30 amplitudes
+    value = ngates * steps * units / wall
     launches = max(1, stats['kernels_launched'])
     # ---- roofline of the dominant kernel --------------------------------------
     if world == 1 and dist is None:
@@ -227,11 +260,14 @@ def main():
                   'unit': 'GB/s', 'frac': stats['bytes_swept'] / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                   'traffic': None, 'note': 'per-GPU bytes swept / event time of rank 0 (includes exchange waits)'}
     out = {
-        'metric': 'gate-applies/sec (30-qubit-shard units), QFT', 'value': value, 'unit': 'gate-applies/s',
+        'metric': 'gate-applies/sec (2^30-amplitude units), QFT', 'value': value, 'unit': 'gate-applies/s',
         'n_gpus': world, 'steps': steps, 'warmup': args.warmup, 'ms_per_step': wall / steps * 1e3,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-        'config': {'workload': f'{n}-qubit QFT complex128, {ngates} gates/step (qc.qft order), '
-                               f'basis-state input, state resident in HBM, 2^{nloc} amplitudes per GPU',
+        'config': {'workload': (f'{n}-qubit QFT complex128, {ngates} gates/step (qc.qft order), basis-state input, '
+                                f'state resident in HBM, 2^{nloc} amplitudes per GPU'
+                                + (' [BASELINE config 2]' if (world == 1 and n == 30) else '')
+                                + (' [BASELINE config 5 ladder: 33/34/35/36 qubits on 1/2/4/8 GPUs]'
+                                   if nloc == 33 else '')),
                    'qubits': n, 'gates_per_step': ngates, 'fusion': fusion,
                    'sharding': 'none' if world == 1 else f'top {gbits} index bits across {world} GPUs'},
         'whole_state_gate_applies_per_s': ngates * steps / wall,
@@ -245,15 +281,21 @@ def main():
       out['exchanges_per_step'] = stats.get('exchanges', 0) / steps
       out['xgmi_bytes_per_rank_per_step'] = stats.get('exchanged_bytes', 0) / steps
       out['exchange_ms_per_step_rank0'] = stats.get('exchange_seconds', 0.0) / steps * 1e3
+      out['exchange_path'] = stats.get('exchange_path')
       if stats.get('exchange_seconds', 0.0) > 0:
         out['xgmi_GBps_per_rank'] = stats.get('exchanged_bytes', 0) / stats['exchange_seconds'] / 1e9
+  if dist is not None:
+    eng.close()
+    dist.destroy_process_group()
+  else:
+    eng.close()
+  if rank == 0:
+    if world == 1 and dist is None and n == 30 and not args.no_ladder_base and fusion != native.QH_FUSE_OFF:
+      out['ladder_base'] = ladder_base(local_rank, fusion)
     if not args.no_cpu_baseline and world == 1:
       out['cpu_baseline'] = cpu_baseline(args, ops, g8)
       out['gpu_over_cpu'] = out['whole_state_gate_applies_per_s'] / out['cpu_baseline']['value']
     print(json.dumps(out))
-  if dist is not None:
-    eng.close()
-    dist.destroy_process_group()
 
 
 if __name__ == '__main__':

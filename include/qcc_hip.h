@@ -117,6 +117,13 @@ int qh_set_fusion(qh_handle h, int level);
 int qh_flush(qh_handle h);
 /* qh_flush + wait for the stream.                                            */
 int qh_sync(qh_handle h);
+/* Gates accepted but not yet executed.  After a failed flush these are the gates
+ * that did NOT run (a planning/allocation failure keeps the whole queue; a failed
+ * per-gate launch keeps that gate and every later one): the caller may change the
+ * fusion level and flush again, or drop them.  (The reference has no counterpart:
+ * xgates.cc:23-67 runs every gate synchronously or exits.)                    */
+int qh_pending_gates(qh_handle h, uint64_t *count);
+int qh_discard_pending(qh_handle h);
 
 /* ---- logical -> physical bit map (global<->local qubit swaps) ----------- */
 /* Records that the DATA of physical bits a and b has been exchanged (by the

@@ -256,21 +256,40 @@ int check_launch(qh_state_s *h) {
   return QH_OK;
 }
 
+// Kernels, op-buffer allocations and events of a handle belong to ITS device, whatever device
+// the calling thread had current (a process may hold handles on several GPUs).
+int use_device(qh_state_s *h) {
+  if (h->dry) return QH_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  return QH_OK;
+}
+
+// Runs the queue.  On failure the gates that did NOT run stay queued (qh_pending_gates):
+// a planning / allocation failure keeps the whole queue, a failed per-gate launch keeps the
+// failing gate and everything after it.  Only a failed launch of a planned sweep leaves the
+// state partially updated; the queue is then dropped and the error says so.
 int flush_impl(qh_state_s *h) {
   if (h->queue.empty()) return QH_OK;
-  int rc = QH_OK;
+  int rc = use_device(h);
+  if (rc) return rc;
   if (h->fusion == QH_FUSE_SWEEP && qh::sweep_supported(h->nloc, h->bw)) {
+    const uint64_t launched0 = h->stats.kernels_launched;
     rc = qh::run_fused(h->queue, h->nloc, h->shard, h->bw, h->d_psi, h->stream, h->dry,
                        &h->sweep, &h->stats, &g_err);
+    if (rc != QH_OK && h->stats.kernels_launched == launched0) return rc;   // nothing ran: queue kept
     if (rc == QH_OK) rc = check_launch(h);
-  } else {
-    for (const auto &r : h->queue) {
-      rc = launch_single(h, r);
-      if (rc) break;
-    }
-    if (rc == QH_OK) rc = check_launch(h);
+    if (rc != QH_OK) g_err += " [sweeps of this flush may have run partially; its gates were dropped]";
+    h->queue.clear();
+    return rc;
   }
-  h->queue.clear();
+  size_t done = 0;
+  for (const auto &r : h->queue) {
+    rc = launch_single(h, r);
+    if (rc == QH_OK) rc = check_launch(h);
+    if (rc) break;
+    ++done;
+  }
+  h->queue.erase(h->queue.begin(), h->queue.begin() + done);
   return rc;
 }
 
@@ -289,7 +308,8 @@ int submit_phys(qh_state_s *h, uint64_t cmask, int tbit, const double g[8]) {
     if (h->queue.size() >= 8192) return flush_impl(h);
     return QH_OK;
   }
-  int rc = launch_single(h, r);
+  int rc = use_device(h);
+  if (rc == QH_OK) rc = launch_single(h, r);
   if (rc == QH_OK) rc = check_launch(h);
   if (rc == QH_OK) h->stats.gates_submitted++;
   return rc;
@@ -614,9 +634,9 @@ int qh_init_product(qh_handle h, int nfactors, const int *nq, const double *cons
 int qh_upload(qh_handle h, const void *host, uint64_t offset, uint64_t count) {
   if (!h || !host || h->dry) return fail(QH_ERR_ARG, "null/dry");
   if (offset + count > (1ull << h->nloc)) return fail(QH_ERR_ARG, "upload range out of bounds");
+  HIP_TRY(hipSetDevice(h->device));
   int rc = flush_impl(h);
   if (rc) return rc;
-  HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipMemcpyAsync((char *)h->d_psi + offset * h->amp_bytes(), host, count * h->amp_bytes(),
                          hipMemcpyHostToDevice, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
@@ -626,9 +646,9 @@ int qh_upload(qh_handle h, const void *host, uint64_t offset, uint64_t count) {
 int qh_download(qh_handle h, void *host, uint64_t offset, uint64_t count) {
   if (!h || !host || h->dry) return fail(QH_ERR_ARG, "null/dry");
   if (offset + count > (1ull << h->nloc)) return fail(QH_ERR_ARG, "download range out of bounds");
+  HIP_TRY(hipSetDevice(h->device));
   int rc = flush_impl(h);
   if (rc) return rc;
-  HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipMemcpyAsync(host, (const char *)h->d_psi + offset * h->amp_bytes(),
                          count * h->amp_bytes(), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
@@ -674,8 +694,19 @@ int qh_set_fusion(qh_handle h, int level) {
 
 int qh_flush(qh_handle h) {
   if (!h) return fail(QH_ERR_ARG, "null handle");
-  if (!h->dry) HIP_TRY(hipSetDevice(h->device));
   return flush_impl(h);
+}
+
+int qh_pending_gates(qh_handle h, uint64_t *count) {
+  if (!h || !count) return fail(QH_ERR_ARG, "null");
+  *count = h->queue.size();
+  return QH_OK;
+}
+
+int qh_discard_pending(qh_handle h) {
+  if (!h) return fail(QH_ERR_ARG, "null handle");
+  h->queue.clear();
+  return QH_OK;
 }
 
 int qh_sync(qh_handle h) {

@@ -58,6 +58,8 @@ SIGNATURES = {
     'qh_set_fusion': (_i32, [_vp, _i32]),
     'qh_flush': (_i32, [_vp]),
     'qh_sync': (_i32, [_vp]),
+    'qh_pending_gates': (_i32, [_vp, ctypes.POINTER(_u64)]),
+    'qh_discard_pending': (_i32, [_vp]),
     'qh_remap_swap': (_i32, [_vp, _i32, _i32]),
     'qh_get_bitmap': (_i32, [_vp, ctypes.POINTER(ctypes.c_int32)]),
     'qh_phys_to_logical': (_i32, [_vp, _u64, ctypes.POINTER(_u64)]),

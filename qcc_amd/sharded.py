@@ -198,6 +198,7 @@ class ShardedState:
             gc = g8.view(np.complex128).reshape(-1, 4)
           cmask = 0 if cq[k] == NO_CTL else 1 << (n - 1 - cq[k])
           self.apply_bits(cmask, tb, gc[k])
+          self.gates -= 1                      # apply_bits counted it; the total is added below
           continue
       if not diag[k]:
         self._seq += 1
@@ -208,6 +209,8 @@ class ShardedState:
         c = n - 1 - cq[k]
         if not 0 <= c < n:
           raise ValueError(f'control qubit {cq[k]} out of range')
+        if c == tb:
+          raise ValueError(f'control == target (qubit {cq[k]})')
         pc = perm[c]
         if pc >= nloc:
           if not (rank >> (pc - nloc)) & 1:
