@@ -13,7 +13,11 @@
  *  - v / yroot / cv / cv_adj implement what they are named after (sqrt(X), sqrt(Y),
  *    controlled sqrt(X) and its adjoint, the matrices of src/lib/ops.py:152-162).
  *    The reference versions apply the gate once per stored state inside a loop
- *    (gates.cc:9-15,48-54,96-118) and are not usable as a spec;
+ *    (gates.cc:9-15,48-54,96-118, SURVEY quirk Q5: libq::v on |0> yields total
+ *    probability 1.5) and libq::v's matrix {(.5,.5),(.5,.5),(.5,-.5),(.5,.5)} is not
+ *    sqrt(X) either (gates.cc:10-11 vs ops.py:152-154): not usable as a spec.  The
+ *    other eleven gates are checked against the reference's own libq for every target
+ *    / ordered pair (tests/golden/g8_libq_gates.npz, tests/test_gpu_libq_facade.py);
  *  - bit order is libq's: target t is index bit t (little-endian).
  */
 #ifndef QCC_LIBQ_FACADE_H_

@@ -54,7 +54,8 @@ typedef struct qh_state_s *qh_handle;
 #define QH_ERR_NOMEM 6          /* device allocation failed                     */
 #define QH_ERR_NO_DEVICE 7      /* no gfx950 device visible                     */
 #define QH_ERR_NONLOCAL 8       /* non-diagonal gate targets a bit held by the
-                                   shard index: exchange first (qh_remap_swap)  */
+                                   shard index: exchange first (qh_exchange_*)  */
+#define QH_ERR_COMM 9           /* RCCL / transport failure (see last_error)    */
 
 /* fusion levels for qh_set_fusion */
 #define QH_FUSE_OFF 0           /* one kernel per gate, launched immediately    */
@@ -134,6 +135,52 @@ int qh_remap_swap(qh_handle h, int phys_bit_a, int phys_bit_b);
 int qh_get_bitmap(qh_handle h, int32_t *phys_of_logical /* [nbits_global] */);
 int qh_phys_to_logical(qh_handle h, uint64_t phys_index, uint64_t *logical);
 int qh_logical_to_phys(qh_handle h, uint64_t logical_index, uint64_t *phys);
+
+/* ---- multi-GPU exchange (the reference has no distributed path) --------------
+ * One process per GPU, each with one handle on its shard (qh_set_shard).  A dense gate whose
+ * target is a shard bit needs the exchange below first; gates on local bits, controls on shard
+ * bits and diagonal gates on shard bits never communicate.  Transport: RCCL send/recv over xGMI
+ * on a second HIP stream (qh_comm_init), or a host-staged callback (qh_comm_init_custom: tests
+ * with several ranks on one GPU, fabrics without peer access).
+ *
+ * qh_exchange_* first run the queued gates, then enqueue the exchange and RETURN: the exchange
+ * proceeds in slabs, slab k leaving as soon as the part of the last queued sweep that writes it
+ * has finished, and the first sweep submitted afterwards starts on slab k as soon as slab k has
+ * arrived (HIP events between the handle's stream and the exchange streams; no host wait).
+ * Every other entry point that touches the state waits for the arrivals first.
+ * The bit map is NOT changed here: the caller records the swap (qh_remap_swap, or its own map). */
+#define QH_COMM_ID_BYTES 128
+/* One round of the host-staged transport: send bytes from send_host[i] to rank peers[i] and
+ * receive the same number of bytes from it into recv_host[i], for all i at once; 0 = ok.   */
+typedef int (*qh_round_fn)(void *user, int npeers, const int *peers, void *const *send_host,
+                           void *const *recv_host, uint64_t bytes);
+typedef struct {
+  uint64_t exchanges;        /* qh_exchange_* calls                                        */
+  uint64_t rounds;           /* grouped send/recv rounds                                   */
+  uint64_t bytes_sent;       /* bytes this rank sent (== bytes received)                   */
+  uint64_t slabs;            /* slabs the exchanges were cut into                          */
+  uint64_t sweeps_overlapped;/* sweeps launched slab-wise around exchanges                 */
+  double span_ms;            /* HIP-event time from the first send to the last landing     */
+} qh_xstats;
+int qh_comm_unique_id(void *id /* QH_COMM_ID_BYTES, rank 0; broadcast by the caller */);
+int qh_comm_init(qh_handle h, int nranks, int rank, const void *id);
+int qh_comm_init_custom(qh_handle h, int nranks, int rank, qh_round_fn fn, void *user);
+int qh_comm_destroy(qh_handle h);
+/* All g = log2(nranks) shard bits <-> local bits [base_bit, base_bit+g): rank r sends block j of
+ * its shard to rank j and receives rank j's block r in its place (all peers at once).
+ * chunk_amps: amplitudes per peer and round (0 = default 2^22).                             */
+int qh_exchange_alltoall(qh_handle h, int base_bit, uint64_t chunk_amps);
+/* Shard bit k (0..g-1) <-> local_bit: the half of the shard whose local_bit differs from this
+ * rank's shard bit k is swapped with rank (r ^ 2^k)'s (one peer, one link).                 */
+int qh_exchange_pair(qh_handle h, int shard_bit, int local_bit, uint64_t chunk_amps);
+/* Self test of the transport on one rank: the two halves of the shard selected by local_bit are
+ * sent to this rank itself and land exchanged (== an X gate on that bit), through the same
+ * rounds / staging / slabs as a real exchange.                                              */
+int qh_exchange_loopback(qh_handle h, int local_bit, uint64_t chunk_amps);
+int qh_exchange_wait(qh_handle h);                 /* host wait for all arrivals             */
+int qh_exchange_stats(qh_handle h, qh_xstats *out);
+/* sum over ranks of `count` doubles, in place (RCCL transport only): norms, probabilities    */
+int qh_comm_allreduce_sum(qh_handle h, double *inout, int count);
 
 /* ---- device-side readers (state.py:24-78) ------------------ */
 int qh_norm2(qh_handle h, double *out);                       /* sum |a|^2 of the shard */

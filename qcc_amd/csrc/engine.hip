@@ -63,6 +63,7 @@ struct qh_state_s {
   double *d_red = nullptr;     // kRedBlocks doubles
   uint64_t *d_redi = nullptr;  // kRedBlocks u64
   qh::SweepBuffers sweep;      // device/pinned op buffers for fused sweeps
+  qh::Comm *comm = nullptr;    // multi-GPU exchange (exchange.hip.h)
   uint64_t amp_bytes() const { return bw == 128 ? 16 : 8; }
   uint64_t local_mask() const { return nloc >= 64 ? ~0ull : ((1ull << nloc) - 1ull); }
 };
@@ -99,7 +100,9 @@ unsigned pick_grid(uint64_t nwork, int per_block) {
   if (blocks < 1) blocks = 1;
   const int cap = grid_cap();
   if (cap > 0 && blocks > (uint64_t)cap) blocks = cap;
-  if (blocks > 0x7fffffffull) blocks = 0x7fffffffull;
+  // HIP refuses launches of 2^32 threads or more (a per-gate kernel over a 2^33-amplitude shard
+  // would be 2^24 blocks of 256): the kernels are grid-stride, so cap the grid
+  if (blocks > (1ull << 23)) blocks = 1ull << 23;
   return (unsigned)blocks;
 }
 
@@ -268,20 +271,31 @@ int use_device(qh_state_s *h) {
 // a planning / allocation failure keeps the whole queue, a failed per-gate launch keeps the
 // failing gate and everything after it.  Only a failed launch of a planned sweep leaves the
 // state partially updated; the queue is then dropped and the error says so.
-int flush_impl(qh_state_s *h) {
-  if (h->queue.empty()) return QH_OK;
+int flush_impl(qh_state_s *h, qh::SlabIO *split = nullptr) {
   int rc = use_device(h);
   if (rc) return rc;
+  std::vector<qh::Arrival> *arr = (h->comm && !h->comm->arrivals.empty()) ? &h->comm->arrivals : nullptr;
+  if (h->queue.empty()) {
+    qh::wait_all_arrivals(arr, h->stream);   // whoever called touches the state next
+    return QH_OK;
+  }
   if (h->fusion == QH_FUSE_SWEEP && qh::sweep_supported(h->nloc, h->bw)) {
     const uint64_t launched0 = h->stats.kernels_launched;
+    qh::SlabIO local;
+    qh::SlabIO *io = split ? split : &local;
+    io->arrivals = arr;
+    io->comm = h->comm;
     rc = qh::run_fused(h->queue, h->nloc, h->shard, h->bw, h->d_psi, h->stream, h->dry,
-                       &h->sweep, &h->stats, &g_err);
+                       &h->sweep, &h->stats, &g_err, h->comm ? io : nullptr);
+    if (!h->dry) qh::wait_all_arrivals(arr, h->stream);   // (a flush that planned no sweep)
+    if (h->comm) h->comm->stats.sweeps_overlapped += io->sweeps_overlapped;
     if (rc != QH_OK && h->stats.kernels_launched == launched0) return rc;   // nothing ran: queue kept
     if (rc == QH_OK) rc = check_launch(h);
     if (rc != QH_OK) g_err += " [sweeps of this flush may have run partially; its gates were dropped]";
     h->queue.clear();
     return rc;
   }
+  qh::wait_all_arrivals(arr, h->stream);
   size_t done = 0;
   for (const auto &r : h->queue) {
     rc = launch_single(h, r);
@@ -474,6 +488,7 @@ int qh_destroy(qh_handle h) {
   if (!h->dry) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    (void)qh_comm_destroy(h);
     qh::free_sweep_buffers(&h->sweep);
     if (h->d_red) (void)hipFree(h->d_red);
     if (h->d_redi) (void)hipFree(h->d_redi);
@@ -557,6 +572,7 @@ int qh_init_basis(qh_handle h, uint64_t index) {
   h->queue.clear();
   if (h->dry) return QH_OK;
   HIP_TRY(hipSetDevice(h->device));
+  if (h->comm) qh::wait_all_arrivals(&h->comm->arrivals, h->stream);
   uint64_t phys;
   qh_logical_to_phys(h, index, &phys);
   HIP_TRY(hipMemsetAsync(h->d_psi, 0, (1ull << h->nloc) * h->amp_bytes(), h->stream));
@@ -598,6 +614,7 @@ int qh_init_product(qh_handle h, int nfactors, const int *nq, const double *cons
   if (entries > (1ull << 25)) return fail(QH_ERR_ARG, "factor tables larger than 2^25 amplitudes");
   h->queue.clear();
   if (h->dry) return QH_OK;
+  if (h->comm) qh::wait_all_arrivals(&h->comm->arrivals, h->stream);
   std::vector<double> tab(2 * std::max<uint64_t>(entries, 1));
   uint64_t off = 0;
   int shift = h->nglob;
@@ -617,7 +634,7 @@ int qh_init_product(qh_handle h, int nfactors, const int *nq, const double *cons
   hipError_t e = hipMemcpyAsync(d_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, h->stream);
   if (e == hipSuccess) {
     const uint64_t n = 1ull << h->nloc;
-    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    const dim3 grid((unsigned)std::min<uint64_t>((n + 255) / 256, 1ull << 22)), block(256);
     const uint64_t idx_high = h->shard << h->nloc;
     if (h->bw == 128)
       hipLaunchKernelGGL(qh::k_init_product<double>, grid, block, 0, h->stream, (double2 *)h->d_psi, n, idx_high, sp, d_tab);
@@ -930,6 +947,318 @@ int qh_plan_export(qh_handle h, void *buf, uint64_t cap, uint64_t *needed) {
   }
   return QH_OK;
 }
+
+}  // extern "C"
+
+// ---- multi-GPU exchange (exchange.hip.h) --------------------------------------------------
+namespace {
+
+#define NCCL_TRY(expr)                                                                     \
+  do {                                                                                     \
+    ncclResult_t r_ = (expr);                                                              \
+    if (r_ != ncclSuccess)                                                                 \
+      return fail(QH_ERR_COMM, "%s: %s (%s:%d)", #expr, qh::rccl().GetErrorString(r_), __FILE__, __LINE__); \
+  } while (0)
+
+int comm_common_init(qh_state_s *h, int nranks, int rank) {
+  if (!h || h->dry) return fail(QH_ERR_ARG, "null/dry handle");
+  if (h->comm) return fail(QH_ERR_ARG, "handle already has a communicator");
+  if (nranks < 1 || (nranks & (nranks - 1)) || rank < 0 || rank >= nranks)
+    return fail(QH_ERR_ARG, "nranks %d must be a power of two, rank %d inside it", nranks, rank);
+  if (h->bw != 128 && h->bw != 64) return fail(QH_ERR_BAD_DTYPE, "bit width");
+  HIP_TRY(hipSetDevice(h->device));
+  auto *c = new qh::Comm;
+  c->nranks = nranks;
+  c->rank = rank;
+  hipError_t e = hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->cstream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreate(&c->t0);
+  if (e == hipSuccess) e = hipEventCreate(&c->t1);
+  if (e != hipSuccess) {
+    delete c;
+    return fail(QH_ERR_HIP, "exchange streams/events: %s", hipGetErrorString(e));
+  }
+  h->comm = c;
+  return QH_OK;
+}
+
+// closes the timing bracket of the previous exchange (waits for it)
+void close_timing(qh::Comm *c) {
+  if (!c->timing_open) return;
+  float ms = 0;
+  if (hipEventSynchronize(c->t1) == hipSuccess && hipEventElapsedTime(&ms, c->t0, c->t1) == hipSuccess)
+    c->stats.span_ms += ms;
+  c->timing_open = false;
+}
+
+// The exchange proper.  `moves`: block value blk of the g bits at `base` goes to `peer`, whose
+// data lands in block value `land`.
+int do_exchange(qh_state_s *h, const std::vector<qh::BlockMove> &moves, int base, int gbits, uint64_t chunk_amps) {
+  qh::Comm *c = h->comm;
+  const int nloc = h->nloc;
+  const uint64_t ab = h->amp_bytes();
+  if (base < 0 || base + gbits > nloc) return fail(QH_ERR_BAD_QUBIT, "exchange bits [%d,%d) outside the %d local bits", base, base + gbits, nloc);
+  HIP_TRY(hipSetDevice(h->device));
+  close_timing(c);
+  // 1. the queued gates, the last sweep cut into slabs
+  const uint64_t blockbits = ((1ull << gbits) - 1) << base;
+  qh::SlabIO io;
+  io.split_last = true;
+  io.avoid = blockbits;
+  io.want_bits = env_int("QH_EXCHANGE_SLAB_BITS", 3);
+  c->pool_used = 0;   // (arrivals of the previous exchange are waited for by this flush)
+  int rc = flush_impl(h, &io);
+  if (rc) return rc;
+  uint64_t slab_mask = io.slab_mask;
+  if (!slab_mask && io.want_bits > 0) {
+    // nothing was queued (or the last sweep could not be cut): slabs still let the NEXT sweep start early
+    slab_mask = qh::pick_slab_bits(nloc, blockbits | 7ull, std::min(io.want_bits, std::max(0, nloc - gbits - 10)), 6);
+  }
+  const int K = 1 << qh::popc(slab_mask);
+  hipEvent_t all_done = nullptr;
+  if (io.slab_done.empty() || std::find(io.slab_done.begin(), io.slab_done.end(), nullptr) != io.slab_done.end()) {
+    all_done = c->event();
+    if (!all_done) return fail(QH_ERR_HIP, "hipEventCreate failed");
+    HIP_TRY(hipEventRecord(all_done, h->stream));
+    io.slab_done.assign(K, all_done);
+  }
+  // 2. geometry of the rounds
+  const uint64_t free_mask = h->local_mask() & ~blockbits & ~slab_mask;
+  const int run_bits = (~free_mask) ? __builtin_ctzll(~free_mask) : 64;
+  if (!chunk_amps) chunk_amps = 1ull << 22;
+  int chunk_bits = 0;
+  while ((2ull << chunk_bits) <= chunk_amps && chunk_bits + 1 <= run_bits) chunk_bits++;
+  const uint64_t n = 1ull << chunk_bits;                       // amplitudes per peer and round
+  const uint64_t nchunks = 1ull << (qh::popc(free_mask) - chunk_bits);
+  const size_t np = moves.size();
+  if (np == 0) return QH_OK;
+  char *psi = (char *)h->d_psi;
+  if (c->custom) {
+    // host-staged transport: synchronous rounds
+    const size_t need = np * n * ab;
+    if (c->h_bytes < need) {
+      if (c->h_send) (void)hipHostFree(c->h_send);
+      if (c->h_recv) (void)hipHostFree(c->h_recv);
+      c->h_send = c->h_recv = nullptr;
+      c->h_bytes = 0;
+      HIP_TRY(hipHostMalloc(&c->h_send, need, hipHostMallocDefault));
+      HIP_TRY(hipHostMalloc(&c->h_recv, need, hipHostMallocDefault));
+      c->h_bytes = need;
+    }
+    std::vector<int> peers(np);
+    std::vector<void *> sp(np), rp(np);
+    for (size_t m = 0; m < np; ++m) {
+      peers[m] = moves[m].peer;
+      sp[m] = (char *)c->h_send + m * n * ab;
+      rp[m] = (char *)c->h_recv + m * n * ab;
+    }
+    for (int k = 0; k < K; ++k) {
+      const uint64_t sv = qh::deposit_bits((uint64_t)k, slab_mask);
+      HIP_TRY(hipEventSynchronize(io.slab_done[k]));
+      if (k == 0) { HIP_TRY(hipEventRecord(c->t0, c->xstream)); }
+      for (uint64_t ci = 0; ci < nchunks; ++ci) {
+        const uint64_t off = qh::deposit_bits(ci << chunk_bits, free_mask) | sv;
+        for (size_t m = 0; m < np; ++m)
+          HIP_TRY(hipMemcpyAsync(sp[m], psi + (off | ((uint64_t)moves[m].blk << base)) * ab, n * ab, hipMemcpyDeviceToHost, c->xstream));
+        HIP_TRY(hipStreamSynchronize(c->xstream));
+        if (c->custom(c->custom_user, (int)np, peers.data(), sp.data(), rp.data(), n * ab) != 0)
+          return fail(QH_ERR_COMM, "host-staged transport: the round callback failed");
+        for (size_t m = 0; m < np; ++m)
+          HIP_TRY(hipMemcpyAsync(psi + (off | ((uint64_t)moves[m].land << base)) * ab, rp[m], n * ab, hipMemcpyHostToDevice, c->xstream));
+        HIP_TRY(hipStreamSynchronize(c->xstream));
+        c->stats.rounds++;
+      }
+      hipEvent_t ev = c->event();
+      if (!ev) return fail(QH_ERR_HIP, "hipEventCreate failed");
+      HIP_TRY(hipEventRecord(ev, c->xstream));
+      c->arrivals.push_back(qh::Arrival{slab_mask, sv, ev});
+    }
+    HIP_TRY(hipEventRecord(c->t1, c->xstream));
+  } else {
+    // RCCL: grouped send/recv per round on xstream, landing copies on cstream, two staging halves
+    if (!c->nccl) return fail(QH_ERR_COMM, "no communicator (qh_comm_init)");
+    const size_t half = np * n * ab;
+    if (c->staging_bytes < 2 * half) {
+      if (c->staging) {
+        HIP_TRY(hipStreamSynchronize(c->cstream));
+        (void)hipFree(c->staging);
+        c->staging = nullptr;
+        c->staging_bytes = 0;
+      }
+      HIP_TRY(hipMalloc(&c->staging, 2 * half));
+      c->staging_bytes = 2 * half;
+    }
+    const ncclDataType_t dt = h->bw == 128 ? ncclDouble : ncclFloat;
+    const size_t cnt = (size_t)n * 2;
+    auto &R = qh::rccl();
+    hipEvent_t copied[2] = {nullptr, nullptr};
+    uint64_t round = 0;
+    for (int k = 0; k < K; ++k) {
+      const uint64_t sv = qh::deposit_bits((uint64_t)k, slab_mask);
+      HIP_TRY(hipStreamWaitEvent(c->xstream, io.slab_done[k], 0));
+      if (k == 0) { HIP_TRY(hipEventRecord(c->t0, c->xstream)); }
+      hipEvent_t last_copy = nullptr;
+      for (uint64_t ci = 0; ci < nchunks; ++ci, ++round) {
+        const int par = (int)(round & 1);
+        const uint64_t off = qh::deposit_bits(ci << chunk_bits, free_mask) | sv;
+        char *stage = (char *)c->staging + par * half;
+        if (copied[par]) HIP_TRY(hipStreamWaitEvent(c->xstream, copied[par], 0));   // this half is free again
+        NCCL_TRY(R.GroupStart());
+        for (size_t m = 0; m < np; ++m) {
+          NCCL_TRY(R.Send(psi + (off | ((uint64_t)moves[m].blk << base)) * ab, cnt, dt, moves[m].peer, c->nccl, c->xstream));
+          NCCL_TRY(R.Recv(stage + m * n * ab, cnt, dt, moves[m].peer, c->nccl, c->xstream));
+        }
+        NCCL_TRY(R.GroupEnd());
+        hipEvent_t landed = c->event();
+        if (!landed) return fail(QH_ERR_HIP, "hipEventCreate failed");
+        HIP_TRY(hipEventRecord(landed, c->xstream));
+        HIP_TRY(hipStreamWaitEvent(c->cstream, landed, 0));
+        for (size_t m = 0; m < np; ++m)
+          HIP_TRY(hipMemcpyAsync(psi + (off | ((uint64_t)moves[m].land << base)) * ab, stage + m * n * ab, n * ab,
+                                 hipMemcpyDeviceToDevice, c->cstream));
+        hipEvent_t cp = c->event();
+        if (!cp) return fail(QH_ERR_HIP, "hipEventCreate failed");
+        HIP_TRY(hipEventRecord(cp, c->cstream));
+        copied[par] = cp;
+        last_copy = cp;
+        c->stats.rounds++;
+      }
+      c->arrivals.push_back(qh::Arrival{slab_mask, sv, last_copy});
+    }
+    HIP_TRY(hipEventRecord(c->t1, c->cstream));
+  }
+  c->timing_open = true;
+  c->stats.exchanges++;
+  c->stats.slabs += K;
+  c->stats.bytes_sent += (uint64_t)np * (1ull << (nloc - gbits)) * ab;
+  return QH_OK;
+}
+
+int log2_exact(int v) {
+  int g = 0;
+  while ((1 << g) < v) ++g;
+  return g;
+}
+
+}  // namespace
+
+extern "C" {
+
+int qh_comm_unique_id(void *id) {
+  if (!id) return fail(QH_ERR_ARG, "null");
+  std::string err;
+  if (!qh::rccl().load(&err)) return fail(QH_ERR_COMM, "%s", err.c_str());
+  static_assert(sizeof(ncclUniqueId) == QH_COMM_ID_BYTES, "id size");
+  NCCL_TRY(qh::rccl().GetUniqueId((ncclUniqueId *)id));
+  return QH_OK;
+}
+
+int qh_comm_init(qh_handle h, int nranks, int rank, const void *id) {
+  if (!id) return fail(QH_ERR_ARG, "null id");
+  std::string err;
+  if (!qh::rccl().load(&err)) return fail(QH_ERR_COMM, "%s", err.c_str());
+  int rc = comm_common_init(h, nranks, rank);
+  if (rc) return rc;
+  ncclUniqueId uid;
+  memcpy(&uid, id, sizeof uid);
+  ncclResult_t r = qh::rccl().CommInitRank(&h->comm->nccl, nranks, uid, rank);
+  if (r != ncclSuccess) {
+    (void)qh_comm_destroy(h);
+    return fail(QH_ERR_COMM, "ncclCommInitRank(%d of %d): %s", rank, nranks, qh::rccl().GetErrorString(r));
+  }
+  return QH_OK;
+}
+
+int qh_comm_init_custom(qh_handle h, int nranks, int rank, qh_round_fn fn, void *user) {
+  if (!fn) return fail(QH_ERR_ARG, "null callback");
+  int rc = comm_common_init(h, nranks, rank);
+  if (rc) return rc;
+  h->comm->custom = fn;
+  h->comm->custom_user = user;
+  return QH_OK;
+}
+
+int qh_comm_destroy(qh_handle h) {
+  if (!h || !h->comm) return QH_OK;
+  qh::Comm *c = h->comm;
+  (void)hipSetDevice(h->device);
+  if (c->xstream) (void)hipStreamSynchronize(c->xstream);
+  if (c->cstream) (void)hipStreamSynchronize(c->cstream);
+  if (c->nccl) (void)qh::rccl().CommDestroy(c->nccl);
+  for (hipEvent_t e : c->pool) (void)hipEventDestroy(e);
+  if (c->t0) (void)hipEventDestroy(c->t0);
+  if (c->t1) (void)hipEventDestroy(c->t1);
+  if (c->staging) (void)hipFree(c->staging);
+  if (c->h_send) (void)hipHostFree(c->h_send);
+  if (c->h_recv) (void)hipHostFree(c->h_recv);
+  if (c->xstream) (void)hipStreamDestroy(c->xstream);
+  if (c->cstream) (void)hipStreamDestroy(c->cstream);
+  delete c;
+  h->comm = nullptr;
+  return QH_OK;
+}
+
+int qh_exchange_alltoall(qh_handle h, int base_bit, uint64_t chunk_amps) {
+  if (!h || !h->comm) return fail(QH_ERR_ARG, "no communicator on this handle (qh_comm_init)");
+  const int g = log2_exact(h->comm->nranks);
+  std::vector<qh::BlockMove> mv;
+  for (int j = 0; j < h->comm->nranks; ++j)
+    if (j != h->comm->rank) mv.push_back(qh::BlockMove{j, j, j});
+  return do_exchange(h, mv, base_bit, g, chunk_amps);
+}
+
+int qh_exchange_pair(qh_handle h, int shard_bit, int local_bit, uint64_t chunk_amps) {
+  if (!h || !h->comm) return fail(QH_ERR_ARG, "no communicator on this handle (qh_comm_init)");
+  const int g = log2_exact(h->comm->nranks);
+  if (shard_bit < 0 || shard_bit >= g) return fail(QH_ERR_BAD_QUBIT, "shard bit %d of %d", shard_bit, g);
+  const int mybit = (h->comm->rank >> shard_bit) & 1;
+  std::vector<qh::BlockMove> mv{qh::BlockMove{h->comm->rank ^ (1 << shard_bit), 1 - mybit, 1 - mybit}};
+  return do_exchange(h, mv, local_bit, 1, chunk_amps);
+}
+
+int qh_exchange_loopback(qh_handle h, int local_bit, uint64_t chunk_amps) {
+  if (!h || !h->comm) return fail(QH_ERR_ARG, "no communicator on this handle (qh_comm_init)");
+  std::vector<qh::BlockMove> mv{qh::BlockMove{h->comm->rank, 0, 1}, qh::BlockMove{h->comm->rank, 1, 0}};
+  return do_exchange(h, mv, local_bit, 1, chunk_amps);
+}
+
+int qh_exchange_wait(qh_handle h) {
+  if (!h || !h->comm) return QH_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  for (const qh::Arrival &a : h->comm->arrivals) HIP_TRY(hipEventSynchronize(a.ev));
+  close_timing(h->comm);
+  return QH_OK;
+}
+
+int qh_exchange_stats(qh_handle h, qh_xstats *out) {
+  if (!h || !out) return fail(QH_ERR_ARG, "null");
+  if (!h->comm) {
+    memset(out, 0, sizeof *out);
+    return QH_OK;
+  }
+  HIP_TRY(hipSetDevice(h->device));
+  close_timing(h->comm);
+  *out = h->comm->stats;
+  return QH_OK;
+}
+
+int qh_comm_allreduce_sum(qh_handle h, double *inout, int count) {
+  if (!h || !h->comm || !inout) return fail(QH_ERR_ARG, "null / no communicator");
+  if (!h->comm->nccl) return fail(QH_ERR_COMM, "qh_comm_allreduce_sum needs the RCCL transport");
+  if (count < 1 || count > kRedBlocks) return fail(QH_ERR_ARG, "count %d", count);
+  HIP_TRY(hipSetDevice(h->device));
+  int rc = flush_impl(h);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(h->d_red, inout, count * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  NCCL_TRY(qh::rccl().AllReduce(h->d_red, h->d_red, (size_t)count, ncclDouble, ncclSum, h->comm->nccl, h->stream));
+  HIP_TRY(hipMemcpyAsync(inout, h->d_red, count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return QH_OK;
+}
+
+}  // extern "C"
+
+extern "C" {
 
 // ---- literal drop-in on host buffers ------------------------------------------
 static qh_handle g_host_h = nullptr;

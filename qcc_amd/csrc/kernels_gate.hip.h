@@ -193,8 +193,8 @@ template <typename R>
 __global__ __launch_bounds__(256) void k_init_product(typename AmpT<R>::type *__restrict__ psi, uint64_t n,
                                                       uint64_t idx_high, ProductSpec sp,
                                                       const double2 *__restrict__ tab) {
-  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
+  // grid-stride: a launch may not exceed 2^32 threads, a 2^33-amplitude shard has more amplitudes
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
   uint64_t logical = idx_high | i;
   if (!sp.identity) {
     const uint64_t phys = logical;
@@ -217,6 +217,7 @@ __global__ __launch_bounds__(256) void k_init_product(typename AmpT<R>::type *__
   a.x = (R)re;
   a.y = (R)im;
   st_amp<true>(psi + i, a);
+  }
 }
 
 // ---- readers ----------------------------------------------------

@@ -187,6 +187,60 @@ class DeviceState:
   def sync(self):
     native.check(self.lib.qh_sync(self.h))
 
+  # -- multi-GPU exchange (include/qcc_hip.h: qh_comm_* / qh_exchange_*) ------------
+  @staticmethod
+  def comm_unique_id():
+    buf = ctypes.create_string_buffer(128)
+    native.check(native.load().qh_comm_unique_id(buf))
+    return buf.raw
+
+  def comm_init(self, nranks, rank, unique_id):
+    """RCCL transport: send/recv over xGMI on the engine's exchange stream."""
+    assert len(unique_id) == 128
+    native.check(self.lib.qh_comm_init(self.h, int(nranks), int(rank), ctypes.c_char_p(unique_id)))
+
+  def comm_init_custom(self, nranks, rank, round_fn):
+    """Host-staged transport: round_fn(peers, send_arrays, recv_arrays) moves one round (uint8 views of
+    the engine's pinned buffers); used with gloo when several ranks share one GPU (tests)."""
+    def _cb(_user, npeers, peers, send, recv, nbytes):
+      try:
+        ps = [peers[i] for i in range(npeers)]
+        sv = [np.ctypeslib.as_array(ctypes.cast(send[i], ctypes.POINTER(ctypes.c_uint8)), shape=(nbytes,)) for i in range(npeers)]
+        rv = [np.ctypeslib.as_array(ctypes.cast(recv[i], ctypes.POINTER(ctypes.c_uint8)), shape=(nbytes,)) for i in range(npeers)]
+        round_fn(ps, sv, rv)
+        return 0
+      except Exception:  # pylint: disable=broad-except
+        import traceback
+        traceback.print_exc()
+        return 1
+    self._round_cb = native.ROUND_FN(_cb)     # keep the trampoline alive as long as the handle
+    native.check(self.lib.qh_comm_init_custom(self.h, int(nranks), int(rank), self._round_cb, None))
+
+  def comm_destroy(self):
+    native.check(self.lib.qh_comm_destroy(self.h))
+
+  def exchange_alltoall(self, base_bit, chunk_amps=0):
+    native.check(self.lib.qh_exchange_alltoall(self.h, int(base_bit), int(chunk_amps)))
+
+  def exchange_pair(self, shard_bit, local_bit, chunk_amps=0):
+    native.check(self.lib.qh_exchange_pair(self.h, int(shard_bit), int(local_bit), int(chunk_amps)))
+
+  def exchange_loopback(self, local_bit, chunk_amps=0):
+    native.check(self.lib.qh_exchange_loopback(self.h, int(local_bit), int(chunk_amps)))
+
+  def exchange_wait(self):
+    native.check(self.lib.qh_exchange_wait(self.h))
+
+  def exchange_stats(self):
+    s = native.QhXStats()
+    native.check(self.lib.qh_exchange_stats(self.h, ctypes.byref(s)))
+    return s.as_dict()
+
+  def allreduce_sum(self, values):
+    a = np.ascontiguousarray(values, dtype=np.float64).copy()
+    native.check(self.lib.qh_comm_allreduce_sum(self.h, a.ctypes.data_as(_dp), a.size))
+    return a
+
   # -- readers --------------------------------------------------------------------
   def norm2(self):
     v = ctypes.c_double()

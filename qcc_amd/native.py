@@ -12,7 +12,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 LIB_PATH = os.environ.get('QCC_HIP_LIB') or os.path.join(PKG, 'libqcc_hip.so')  # env: A/B builds only
 SOURCES = [os.path.join(PKG, 'csrc', f) for f in
-           ('engine.hip', 'kernels_gate.hip.h', 'kernels_sweep.hip.h', 'planner.h',
+           ('engine.hip', 'kernels_gate.hip.h', 'kernels_sweep.hip.h', 'planner.h', 'exchange.hip.h',
             'sweep_island_rb2.inc', 'sweep_island_rb3.inc', 'sweep_island_rb4.inc',
             'sweep_island_rb5.inc', 'sweep_island_f32_rb2.inc', 'sweep_island_f32_rb3.inc',
             'sweep_island_f32_rb4.inc', 'sweep_island_f32_rb5.inc', 'libq_facade.cc')]
@@ -21,7 +21,7 @@ HEADER = os.path.join(ROOT, 'include', 'qcc_hip.h')
 
 QH_OK = 0
 QH_ERR_BAD_QUBIT, QH_ERR_SAME_QUBIT, QH_ERR_BAD_DTYPE, QH_ERR_HIP = 1, 2, 3, 4
-QH_ERR_ARG, QH_ERR_NOMEM, QH_ERR_NO_DEVICE, QH_ERR_NONLOCAL = 5, 6, 7, 8
+QH_ERR_ARG, QH_ERR_NOMEM, QH_ERR_NO_DEVICE, QH_ERR_NONLOCAL, QH_ERR_COMM = 5, 6, 7, 8, 9
 QH_FUSE_OFF, QH_FUSE_SWEEP = 0, 1
 
 _u64, _i32, _vp, _dp = ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)
@@ -79,6 +79,32 @@ SIGNATURES = {
     'qh_host_apply1': (_i32, [_vp, _dp, _i32, _i32, _i32]),
     'qh_host_applyc': (_i32, [_vp, _dp, _i32, _i32, _i32, _i32]),
 }
+
+
+class QhXStats(ctypes.Structure):
+  _fields_ = [('exchanges', _u64), ('rounds', _u64), ('bytes_sent', _u64), ('slabs', _u64),
+              ('sweeps_overlapped', _u64), ('span_ms', ctypes.c_double)]
+
+  def as_dict(self):
+    return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+# one round of the host-staged transport (include/qcc_hip.h: qh_round_fn)
+ROUND_FN = ctypes.CFUNCTYPE(ctypes.c_int, _vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(_vp),
+                            ctypes.POINTER(_vp), _u64)
+
+SIGNATURES.update({
+    'qh_comm_unique_id': (_i32, [_vp]),
+    'qh_comm_init': (_i32, [_vp, _i32, _i32, _vp]),
+    'qh_comm_init_custom': (_i32, [_vp, _i32, _i32, ROUND_FN, _vp]),
+    'qh_comm_destroy': (_i32, [_vp]),
+    'qh_exchange_alltoall': (_i32, [_vp, _i32, _u64]),
+    'qh_exchange_pair': (_i32, [_vp, _i32, _i32, _u64]),
+    'qh_exchange_loopback': (_i32, [_vp, _i32, _u64]),
+    'qh_exchange_wait': (_i32, [_vp]),
+    'qh_exchange_stats': (_i32, [_vp, ctypes.POINTER(QhXStats)]),
+    'qh_comm_allreduce_sum': (_i32, [_vp, _dp, _i32]),
+})
 
 
 class QhError(RuntimeError):

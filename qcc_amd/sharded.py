@@ -23,10 +23,22 @@ equal r, in its own HBM, behind its own engine handle.  Per gate:
 There is no collective on the data path other than that exchange; reductions (norm,
 arg-max) are 8-16 byte all-reduces / all-gathers.
 
+The exchange itself runs BEHIND THE C-ABI (qh_exchange_alltoall / qh_exchange_pair,
+qcc_amd/csrc/exchange.hip.h): ncclSend/ncclRecv on the engine's own exchange stream, landing
+copies on a third stream, and -- cut into slabs -- overlapped with the last sweep before and the
+first sweep after it on the compute stream (HIP events, no host wait).  This module only routes
+gates, keeps the logical->physical bit map and hands RCCL's unique id around through
+torch.distributed (control plane).  `self.exchange_path` says which path is live:
+  'rccl'        engine-native RCCL (default with the nccl backend),
+  'host-staged' engine-native rounds through a torch.distributed/gloo callback (several ranks
+                sharing one GPU: tests),
+  'torch-p2p'   torch.distributed.batch_isend_irecv on torch views of the shard -- the CPU test
+                double (gloo, `engine_factory`), or QCC_EXCHANGE=torch.
+
 The local engine is qcc_amd.device.DeviceState attached to a torch CUDA tensor
 (so torch.distributed can address the same HBM).  Tests substitute a CPU engine
 and the gloo backend through `engine_factory` to exercise exactly this routing /
-exchange / bit-map code with world_size 2 and 4.
+bit-map code with world_size 2 and 4.
 """
 import math
 import os
@@ -96,6 +108,46 @@ class ShardedState:
     self.exchanged_bytes = 0
     self.exchange_seconds = 0.0
     self.gates = 0
+    self.exchange_path = 'torch-p2p'
+    self._x0 = {}
+    self._native_chunk = int(os.environ.get('QCC_EXCHANGE_CHUNK_AMPS', '0')) or self.chunk
+    if self.world > 1 or os.environ.get('QCC_EXCHANGE') == 'native':
+      self._init_native_exchange()
+
+  def _init_native_exchange(self):
+    """Engine-native transport when the engine is the HIP one (see the module docstring)."""
+    if not hasattr(self.eng, 'comm_init') or os.environ.get('QCC_EXCHANGE') == 'torch':
+      return
+    dist, torch = self.dist, self.torch
+    try:
+      if dist.get_backend() == 'gloo':
+        def round_fn(peers, send, recv):
+          ops = []
+          for p, s_, r_ in zip(peers, send, recv):
+            ops.append(dist.P2POp(dist.isend, torch.from_numpy(s_), p))
+            ops.append(dist.P2POp(dist.irecv, torch.from_numpy(r_), p))
+          for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        self.eng.comm_init_custom(self.world, self.rank, round_fn)
+        self.exchange_path = 'host-staged'
+      else:
+        box = [self.eng.comm_unique_id() if self.rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        self.eng.comm_init(self.world, self.rank, box[0])
+        self.exchange_path = 'rccl'
+    except Exception as e:  # pylint: disable=broad-except
+      # every rank must take the same path: agree on success
+      self.exchange_path = f'torch-p2p (engine-native transport unavailable: {e})'
+    ok = torch.tensor([1 if self.exchange_path in ('rccl', 'host-staged') else 0], dtype=torch.int32,
+                      device=self._red_device())
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) == 0 and self.exchange_path in ('rccl', 'host-staged'):
+      self.eng.comm_destroy()
+      self.exchange_path = 'torch-p2p (another rank could not start the engine-native transport)'
+
+  @property
+  def _native(self):
+    return self.exchange_path in ('rccl', 'host-staged')
 
   # ------------------------------------------------------------------ helpers
   def _phys_mask(self, logical_mask):
@@ -270,6 +322,17 @@ class ShardedState:
 
   def _exchange(self, shard_phys_bit, base=None):
     import time
+    if self._native:
+      # asynchronous: queued sweeps, rounds and the following sweeps are ordered by HIP events
+      # inside the engine; its exchange timer is a HIP-event span (stats())
+      if self.exchange_mode == 'alltoall':
+        base = self.nloc - self.g if base is None else int(base)
+        self.eng.exchange_alltoall(base, self._native_chunk)
+        self._record_all(base)
+      else:
+        self.eng.exchange_pair(shard_phys_bit - self.nloc, self.nloc - 1, self._native_chunk)
+        self._record_pair(shard_phys_bit)
+      return
     self.eng.sync()                      # local kernels first: the timer below is the exchange alone
     t0 = time.perf_counter()
     if self.exchange_mode == 'alltoall':
@@ -347,12 +410,24 @@ class ShardedState:
     self._swap_all(chunks())
     if self.buf.is_cuda:
       torch.cuda.synchronize()
+    self._record_all(base)
+
+  def _record_all(self, base):
+    g = self.g
     for k in range(g):                               # shard bit k <-> local bit base+k
       a_phys, b_phys = self.nloc + k, base + k
       la, lb = self.perm.index(a_phys), self.perm.index(b_phys)
       self.perm[la], self.perm[lb] = b_phys, a_phys
     self.exchanges += 1
-    self.exchanged_bytes += (P - 1) * (1 << (self.nloc - g)) * 16
+    self.exchanged_bytes += (self.world - 1) * (1 << (self.nloc - g)) * 16
+
+  def _record_pair(self, shard_phys_bit):
+    top = self.nloc - 1
+    la = self.perm.index(shard_phys_bit)
+    lb = self.perm.index(top)
+    self.perm[la], self.perm[lb] = top, shard_phys_bit
+    self.exchanges += 1
+    self.exchanged_bytes += (1 << top) * 16
 
   def _exchange_pair(self, shard_phys_bit):
     """Swap the data of physical shard bit with the top local bit (pairwise, in place)."""
@@ -371,12 +446,7 @@ class ShardedState:
                    for off in range(0, half, self.chunk))
     if self.buf.is_cuda:
       torch.cuda.synchronize()
-    # bookkeeping: the two logical bits trade physical homes
-    la = self.perm.index(shard_phys_bit)
-    lb = self.perm.index(top)
-    self.perm[la], self.perm[lb] = top, shard_phys_bit
-    self.exchanges += 1
-    self.exchanged_bytes += half * 16
+    self._record_pair(shard_phys_bit)                 # the two logical bits trade physical homes
 
   # ------------------------------------------------------------------ readers
   def flush(self):
@@ -446,6 +516,13 @@ class ShardedState:
     s['exchanges'] = self.exchanges
     s['exchanged_bytes'] = self.exchanged_bytes
     s['exchange_seconds'] = self.exchange_seconds
+    s['exchange_path'] = self.exchange_path
+    if self._native:
+      x = self.eng.exchange_stats()
+      s['exchange_seconds'] = (x['span_ms'] - self._x0.get('span_ms', 0.0)) * 1e-3   # HIP events, first send .. last landing
+      s['exchange_rounds'] = x['rounds'] - self._x0.get('rounds', 0)
+      s['exchange_slabs'] = x['slabs'] - self._x0.get('slabs', 0)
+      s['sweeps_overlapped_with_exchange'] = x['sweeps_overlapped'] - self._x0.get('sweeps_overlapped', 0)
     return s
 
   def reset_stats(self):
@@ -453,6 +530,7 @@ class ShardedState:
     self.exchanges = 0
     self.exchanged_bytes = 0
     self.exchange_seconds = 0.0
+    self._x0 = self.eng.exchange_stats() if self._native else {}
 
   def close(self):
     self.eng.sync()

@@ -150,3 +150,30 @@ def test_config5_shard_size_through_sharded_layer():
   finally:
     st.close()
     dist.destroy_process_group()
+
+
+def test_config5_shard_per_gate_kernels():
+  """The unfused kernels on a 2^33-amplitude shard (2^32 pairs per launch: more work items than
+  one HIP launch may have threads -- the grid is capped and the kernels stride)."""
+  ops, g8, _cut = _split_stream()
+  pick = [k for k in range(len(ops)) if ops[k, 1] >= G][:40] + [k for k in range(len(ops)) if ops[k, 1] == G + 1][:3]
+  pick = sorted(set(pick))
+  x = (5 << NLOC) | (0x1B2CB9A5E3 & ((1 << NLOC) - 1))
+  try:
+    st = device.DeviceState(NLOC, 128, fusion=native.QH_FUSE_OFF)
+  except native.QhError as e:
+    if e.code == native.QH_ERR_NOMEM:
+      pytest.skip(str(e))
+    raise
+  with st:
+    st.set_shard(N, 5)
+    st.init_basis(x)
+    st.run_stream(ops[pick], g8[pick])
+    ps = ProductState(N, x)
+    for k in pick:
+      ps.run(ops, g8, k, k + 1)
+    idx, amp = _windows(st, np.random.default_rng(90), count=6)
+    want = ps.amplitudes(_phys_to_logical(st, 5, idx, N))
+    assert np.max(np.abs(want)) > 1e-6
+    assert np.max(np.abs(amp - want)) < 1e-12
+    assert abs(st.norm2() - 1.0) < 1e-10

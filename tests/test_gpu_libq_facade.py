@@ -71,3 +71,90 @@ def test_transpiled_qft12_runs_on_gpu_and_matches_reference_libq(golden_dir, tmp
   ref = np.zeros(4096, dtype=np.complex128)
   ref[g2['libq_state']] = g2['amp']
   assert np.max(np.abs(got - ref)) < 2e-6          # reference libq is float and prints 6 decimals
+
+
+def _build_driver(tmp_path):
+  exe = tmp_path / 'libq_driver'
+  libdir = os.path.join(ROOT, 'qcc_amd')
+  subprocess.check_call(['g++', '-std=c++17', '-O2', os.path.join(ROOT, 'tests', 'libq_driver.cc'),
+                         '-I' + os.path.join(ROOT, 'include'), '-L' + libdir, '-lqcc_hip',
+                         '-Wl,-rpath,' + libdir, '-o', str(exe)])
+  return exe
+
+
+def _run_driver(exe, tmp_path, cases):
+  inp, outp = tmp_path / 'cases.txt', tmp_path / 'dense.bin'
+  with open(inp, 'w') as f:
+    f.write(f'{len(cases)}\n')
+    for w, init, ops in cases:
+      f.write(f'{w} {init} {len(ops)}\n')
+      for name, a, b, c, gamma in ops:
+        f.write(f'{name} {a} {b} {c} {gamma!r}\n')
+  subprocess.check_call([str(exe), str(inp), str(outp)], stdout=subprocess.DEVNULL)
+  raw = np.fromfile(outp, dtype=np.complex128)
+  out, off = [], 0
+  for w, _, _ in cases:
+    out.append(raw[off:off + (1 << w)])
+    off += 1 << w
+  assert off == raw.size
+  return out
+
+
+def test_libq_gate_set_matches_reference_libq(golden_dir, tmp_path):
+  """SURVEY 8a row A7 (src/libq/gates.cc:9-151): x, y, z, h, t, u1, cu1, cx, cz, ccx, walsh through
+  include/libq.h on the GPU -- every target / every ordered pair at 6 qubits on a dense entangled
+  state, sparse inputs, and two QFT adders as the reference's dumper transpiles them -- against what
+  the reference's own libq (oracle/_ref/libq.a, float) computed for the identical calls (golden G8)."""
+  from tests.test_oracle_golden import libq_cases
+  cases = libq_cases(golden_dir)
+  exe = _build_driver(tmp_path)
+  got = _run_driver(exe, tmp_path, [(w, init, ops) for w, init, ops, _ in cases])
+  names = set()
+  for (w, init, ops, dense), g in zip(cases, got):
+    names |= {o[0] for o in ops}
+    err = np.max(np.abs(g - dense))
+    assert err < 3e-6, (w, init, ops[-1], err)          # the reference is complex<float>
+    assert abs(np.vdot(g, g).real - 1) < 1e-12          # ours is complex128
+  assert names >= {'x', 'y', 'z', 'h', 't', 'u1', 'cu1', 'cx', 'cz', 'ccx', 'walsh'}
+
+
+def test_libq_root_gates_match_ops_matrices(oracle, tmp_path):
+  """v, yroot, cv, cv_adj: the reference's libq versions are broken (gates.cc:9-15,48-54,96-118 apply
+  the gate once per stored state), so the facade implements the matrices of
+  src/lib/ops.py:152-162 (sqrt(X), sqrt(Y), controlled sqrt(X) and its adjoint) and is checked
+  against the dense oracle with those matrices."""
+  from qcc_amd import gates
+  w = 6
+  prep = [('walsh', w, 0, 0, 0.0)] + [('u1', i, 0, 0, 0.21 * (i + 1)) for i in range(w)] + [('cu1', 0, 4, 0, 0.6), ('h', 2, 0, 0, 0.0)]
+  cases = []
+  for t in range(w):
+    cases.append((w, 0b011010, prep + [('v', t, 0, 0, 0.0)]))
+    cases.append((w, 0b011010, prep + [('yroot', t, 0, 0, 0.0)]))
+  for c in range(w):
+    for t in range(w):
+      if c != t:
+        cases.append((w, 0b110001, prep + [('cv', c, t, 0, 0.0)]))
+        cases.append((w, 0b110001, prep + [('cv_adj', c, t, 0, 0.0)]))
+  got = _run_driver(_build_driver(tmp_path), tmp_path, cases)
+  import cmath
+  s = 1 / np.sqrt(2)
+  v = np.asarray(gates.vgate(), dtype=np.complex128).reshape(2, 2)
+  mats = {'h': np.array([[s, s], [s, -s]]), 'v': v, 'yroot': np.asarray(gates.yroot(), dtype=np.complex128).reshape(2, 2),
+          'cv': v, 'cv_adj': v.conj().T}
+  rev = np.array([int(format(k, f'0{w}b')[::-1], 2) for k in range(1 << w)])
+  for (w_, init, ops), g in zip(cases, got):
+    psi = np.zeros(1 << w, dtype=np.complex128)
+    psi[int(format(init, f'0{w}b')[::-1], 2)] = 1
+    for name, a, b, c, gamma in ops:
+      if name == 'walsh':
+        for i in range(a):
+          oracle.apply1(psi, mats['h'].reshape(4), w, i)
+      elif name == 'u1':
+        oracle.apply1(psi, np.array([1, 0, 0, cmath.exp(1j * np.float32(gamma))]), w, a)
+      elif name == 'cu1':
+        oracle.applyc(psi, np.array([1, 0, 0, cmath.exp(1j * np.float32(gamma))]), w, a, b)
+      elif name in ('h', 'v', 'yroot'):
+        oracle.apply1(psi, mats[name].reshape(4), w, a)
+      else:
+        oracle.applyc(psi, mats[name].reshape(4), w, a, b)
+    assert np.max(np.abs(g - psi[rev])) < 1e-7, ops[-1]   # float angles in the u1 calls

@@ -40,7 +40,7 @@ def _gate_pool(rng):
 
 @pytest.mark.parametrize('fusion', FUSIONS)
 def test_golden_single_and_controlled(golden_dir, fusion):
-  for fname in ('g3_single.npz', 'g4_ctl_n6.npz', 'g4_ctl_n9.npz'):
+  for fname in ('g3_single.npz', 'g3_single_n10.npz') + tuple(f'g4_ctl_n{n}.npz' for n in (6, 7, 8, 9, 10)):
     g = np.load(os.path.join(golden_dir, fname))
     n = int(g['nbits'])
     with device.DeviceState(n, 128, fusion=fusion) as st:
@@ -208,8 +208,22 @@ def test_readers(oracle):
     assert got[77] == 1 and np.count_nonzero(got) == 1
 
 
-def test_qft22_sampled_golden(golden_dir):
-  g = np.load(os.path.join(golden_dir, 'g6_qft22.npz'))
+def test_supremacy20_sampled_golden(golden_dir):
+  """G9: the reference's 20-qubit depth-20 supremacy run (trace + sampled amplitudes)."""
+  g = np.load(os.path.join(golden_dir, 'g9_supremacy_n20_s0.npz'))
+  n = int(g['nbits'])
+  for fusion in FUSIONS:
+    with device.DeviceState(n, 128, fusion=fusion) as st:
+      st.init_basis(int(g['init_index']))
+      st.run_stream(g['ops'], g['gates'])
+      got = st.download()
+    assert np.max(np.abs(got[g['idx']] - g['amp'])) <= 1e-12
+    assert abs(np.vdot(got, got).real - float(g['norm2'])) < 1e-11
+
+
+@pytest.mark.parametrize('nq', [22, 24, 26])
+def test_qft22_sampled_golden(golden_dir, nq):
+  g = np.load(os.path.join(golden_dir, f'g6_qft{nq}.npz'))
   n, x = int(g['nbits']), int(g['x'])
   ops, g8 = workloads.qft_stream(range(n)).arrays()
   for fusion in FUSIONS:

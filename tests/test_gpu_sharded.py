@@ -51,6 +51,7 @@ def _worker(rank, world, port, n, mode, out_dir):
   from qcc_amd import sharded
   st = sharded.ShardedState(n, fusion=1, local_rank=0, chunk_amps=1 << 16, exchange=mode)
   assert type(st.eng).__module__ == 'qcc_amd.device'
+  assert st.exchange_path == 'host-staged'          # the engine's own exchange, rounds carried by gloo
   ops, g8 = _stream(n, 5)
   st.init_basis(0b101101)
   st.run_stream(ops, g8)
@@ -58,7 +59,9 @@ def _worker(rank, world, port, n, mode, out_dir):
   full = st.gather_logical()
   n2 = st.norm2_global()
   if rank == 0:
-    np.savez(os.path.join(out_dir, 'res.npz'), psi=full, norm2=n2, exchanges=st.exchanges)
+    xs = st.stats()
+    np.savez(os.path.join(out_dir, 'res.npz'), psi=full, norm2=n2, exchanges=st.exchanges, rounds=xs['exchange_rounds'],
+             overlapped=xs['sweeps_overlapped_with_exchange'])
   dist.barrier()
   st.close()
   dist.destroy_process_group()
@@ -77,4 +80,4 @@ def test_sharded_hip_engines_one_gpu(oracle, tmp_path, world, mode):
   oracle.run_stream(want, n, ops, g8)
   assert np.max(np.abs(res['psi'] - want)) < 1e-11
   assert abs(float(res['norm2']) - 1) < 1e-11
-  assert int(res['exchanges']) >= 1
+  assert int(res['exchanges']) >= 1 and int(res['rounds']) >= 1

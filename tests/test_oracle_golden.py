@@ -23,8 +23,9 @@ def _load(golden_dir, name):
   return np.load(os.path.join(golden_dir, name), allow_pickle=False)
 
 
-def test_single_qubit_every_target(oracle, golden_dir):
-  g = _load(golden_dir, 'g3_single.npz')
+@pytest.mark.parametrize('fname', ['g3_single.npz', 'g3_single_n10.npz'])
+def test_single_qubit_every_target(oracle, golden_dir, fname):
+  g = _load(golden_dir, fname)
   n = int(g['nbits'])
   for name, gate, out in zip(g['names'], g['gates'], g['outs']):
     psi = g['psi0'].copy()
@@ -32,7 +33,7 @@ def test_single_qubit_every_target(oracle, golden_dir):
     assert np.max(np.abs(psi - out)) <= TOL128, name
 
 
-@pytest.mark.parametrize('fname', ['g4_ctl_n6.npz', 'g4_ctl_n9.npz'])
+@pytest.mark.parametrize('fname', [f'g4_ctl_n{n}.npz' for n in (6, 7, 8, 9, 10)])
 def test_controlled_every_pair(oracle, golden_dir, fname):
   g = _load(golden_dir, fname)
   n = int(g['nbits'])
@@ -71,6 +72,75 @@ def test_recorded_traces(oracle, golden_dir):
     oracle.run_stream(psi, int(g['nbits']), g['ops'], g['gates'])
     err = np.max(np.abs(psi - g['final']))
     assert err <= 5e-14, (os.path.basename(f), err)
+
+
+def test_supremacy20_sampled(oracle, golden_dir):
+  """G9: 20-qubit supremacy circuit of the reference (trace + sampled amplitudes)."""
+  g = _load(golden_dir, 'g9_supremacy_n20_s0.npz')
+  n = int(g['nbits'])
+  psi = np.zeros(1 << n, dtype=np.complex128)
+  psi[int(g['init_index'])] = 1
+  oracle.run_stream(psi, n, g['ops'], g['gates'])
+  assert np.max(np.abs(psi[g['idx']] - g['amp'])) < 5e-15
+  assert abs(np.vdot(psi, psi).real - float(g['norm2'])) < 1e-12
+
+
+def libq_cases(golden_dir):
+  """Decodes g8_libq_gates.npz: [(width, initval, [(name, a, b, c, gamma)], dense complex64)]."""
+  g = _load(golden_dir, 'g8_libq_gates.npz')
+  names = [str(x) for x in g['op_names']]
+  out, io, off = [], 0, 0
+  for w, init, nops in g['case_head']:
+    ops = [(names[int(r[0])], int(r[1]), int(r[2]), int(r[3]), float(gm))
+           for r, gm in zip(g['case_ops'][io:io + nops], g['case_gamma'][io:io + nops])]
+    io += int(nops)
+    out.append((int(w), int(init), ops, g['dense'][off:off + (1 << int(w))]))
+    off += 1 << int(w)
+  return out
+
+
+def test_reference_libq_gate_set_equals_dense_semantics(oracle, golden_dir):
+  """A7 (src/libq/gates.cc:9-151): what the reference's sparse float libq computed for x, y, z, h,
+  t, u1, cu1, cx, cz, ccx, walsh on every target / ordered pair equals the dense 2x2 semantics of
+  apply1/applyc (libq target t = index bit t = reference qubit width-1-t), to float accuracy.
+  This pins the mapping the GPU facade (include/libq.h) implements."""
+  import cmath
+  s = 1 / np.sqrt(2)
+  mats = {'x': [0, 1, 1, 0], 'y': [0, -1j, 1j, 0], 'z': [1, 0, 0, -1], 'h': [s, s, s, -s],
+          't': [1, 0, 0, cmath.exp(1j * np.pi / 4)]}
+  cases = libq_cases(golden_dir)
+  assert len(cases) >= 190
+  seen = set()
+  for w, init, ops, dense in cases:
+    psi = np.zeros(1 << w, dtype=np.complex128)
+    psi[int(format(init, f'0{w}b')[::-1], 2)] = 1          # libq basis state -> reference (big-endian) index
+    q = lambda t: t                                        # noqa: E731  index bit t of libq == qubit t after the flip
+    for name, a, b, c, gamma in ops:
+      seen.add(name)
+      if name == 'walsh':
+        for i in range(a):
+          oracle.apply1(psi, np.array(mats['h'], dtype=np.complex128), w, q(i))
+      elif name in mats:
+        oracle.apply1(psi, np.array(mats[name], dtype=np.complex128), w, q(a))
+      elif name == 'u1':
+        oracle.apply1(psi, np.array([1, 0, 0, cmath.exp(1j * np.float32(gamma))]), w, q(a))
+      elif name == 'cu1':
+        oracle.applyc(psi, np.array([1, 0, 0, cmath.exp(1j * np.float32(gamma))]), w, q(a), q(b))
+      elif name == 'cx':
+        oracle.applyc(psi, np.array(mats['x'], dtype=np.complex128), w, q(a), q(b))
+      elif name == 'cz':
+        oracle.applyc(psi, np.array(mats['z'], dtype=np.complex128), w, q(a), q(b))
+      elif name == 'ccx':                                  # no native doubly-controlled call: by index arithmetic
+        idx = np.arange(1 << w)
+        bit = lambda i, k: (i >> (w - 1 - k)) & 1          # noqa: E731
+        sel = (bit(idx, q(a)) == 1) & (bit(idx, q(b)) == 1)
+        psi = np.where(sel, psi[idx ^ (1 << (w - 1 - q(c)))], psi)
+      else:
+        raise AssertionError(name)
+    # reference index (big-endian qubit order) -> libq basis state: bit reversal
+    rev = np.array([int(format(k, f'0{w}b')[::-1], 2) for k in range(1 << w)])
+    assert np.max(np.abs(psi[rev] - dense)) < 3e-6, (w, init, ops[-1])
+  assert seen >= {'x', 'y', 'z', 'h', 't', 'u1', 'cu1', 'cx', 'cz', 'ccx', 'walsh'}
 
 
 def test_negative_controls_are_covered(golden_dir):
