@@ -66,9 +66,17 @@ def set_host_executor(ex):
 
 
 def _default_device_factory(nbits, bit_width):
-    from qcc_amd import device
     fusion = native.QH_FUSE_OFF if os.environ.get('QCC_FUSION', '1') == '0' else native.QH_FUSE_SWEEP
-    return device.DeviceState(nbits, bit_width, fusion=fusion)
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world > 1 and nbits >= 2 * max(1, world.bit_length() - 1) + 2:
+        # one process per GPU (torchrun): the register shards by its top log2(WORLD_SIZE) index
+        # bits and every rank runs the same script (north_star: "the circuit.qc() Python API so
+        # every algorithm runs unmodified"); registers too small to shard stay replicated
+        from qcc_amd import sharded
+        return sharded.ShardedDevice(nbits, bit_width, fusion=fusion)
+    from qcc_amd import device
+    return device.DeviceState(nbits, bit_width, fusion=fusion,
+                              device=int(os.environ.get('LOCAL_RANK', '0')) if world > 1 else 0)
 
 
 def make_device_state(nbits, bit_width):

@@ -52,8 +52,8 @@ def _is_diag(g4):
   return g4[1] == 0 and g4[2] == 0
 
 
-def _hip_engine_factory(nloc, local_rank, fusion):
-  """(engine, flat float64 torch view of the shard) on cuda:local_rank."""
+def _hip_engine_factory(nloc, local_rank, fusion, bit_width=128):
+  """(engine, flat real-valued torch view of the shard) on cuda:local_rank."""
   import torch
   from qcc_amd import device
   if not torch.cuda.is_available():
@@ -61,16 +61,16 @@ def _hip_engine_factory(nloc, local_rank, fusion):
                        'runtimes are mapped (see qcc_amd.native._preload_torch_runtime): import torch first or '
                        'launch through torchrun / set QCC_PRELOAD_TORCH=1')
   torch.cuda.set_device(local_rank)
-  buf = torch.zeros(2 << nloc, dtype=torch.float64, device=f'cuda:{local_rank}')
-  eng = device.DeviceState(nloc, 128, device=local_rank, fusion=fusion, device_ptr=buf.data_ptr())
+  buf = torch.zeros(2 << nloc, dtype=torch.float64 if bit_width == 128 else torch.float32, device=f'cuda:{local_rank}')
+  eng = device.DeviceState(nloc, bit_width, device=local_rank, fusion=fusion, device_ptr=buf.data_ptr())
   return eng, buf
 
 
 class ShardedState:
-  """complex128 state sharded by its top log2(P) physical index bits."""
+  """State (complex128, or complex64 with bit_width=64) sharded by its top log2(P) physical index bits."""
 
   def __init__(self, nbits, fusion=1, local_rank=None, *, engine_factory=None, backend=None,
-               chunk_amps=1 << 22, exchange='alltoall'):
+               chunk_amps=1 << 22, exchange='alltoall', bit_width=128):
     import torch
     import torch.distributed as dist
     self.torch, self.dist = torch, dist
@@ -93,7 +93,10 @@ class ShardedState:
     self.nloc = self.nbits - self.g
     assert self.nloc >= 2, 'shard too small'
     local_rank = int(os.environ.get('LOCAL_RANK', '0')) if local_rank is None else local_rank
-    factory = engine_factory or (lambda nloc: _hip_engine_factory(nloc, local_rank, fusion))
+    self.bit_width = int(bit_width)
+    self.amp_bytes = 16 if self.bit_width == 128 else 8
+    self.cdtype = np.complex128 if self.bit_width == 128 else np.complex64
+    factory = engine_factory or (lambda nloc: _hip_engine_factory(nloc, local_rank, fusion, self.bit_width))
     self.eng, self.buf = factory(self.nloc)
     # logical bit b (0 = least significant; qubit q is bit nbits-1-q) -> physical bit
     self.perm = list(range(self.nbits))
@@ -419,7 +422,7 @@ class ShardedState:
       la, lb = self.perm.index(a_phys), self.perm.index(b_phys)
       self.perm[la], self.perm[lb] = b_phys, a_phys
     self.exchanges += 1
-    self.exchanged_bytes += (self.world - 1) * (1 << (self.nloc - g)) * 16
+    self.exchanged_bytes += (self.world - 1) * (1 << (self.nloc - g)) * self.amp_bytes
 
   def _record_pair(self, shard_phys_bit):
     top = self.nloc - 1
@@ -427,7 +430,7 @@ class ShardedState:
     lb = self.perm.index(top)
     self.perm[la], self.perm[lb] = top, shard_phys_bit
     self.exchanges += 1
-    self.exchanged_bytes += (1 << top) * 16
+    self.exchanged_bytes += (1 << top) * self.amp_bytes
 
   def _exchange_pair(self, shard_phys_bit):
     """Swap the data of physical shard bit with the top local bit (pairwise, in place)."""
@@ -467,7 +470,7 @@ class ShardedState:
   def argmax_global(self):
     """(logical index, probability) of the likeliest basis state."""
     li, p = self.eng.argmax()
-    phys = (self.rank << self.nloc) | li
+    phys = (self.rank << self.nloc) | (li & ((1 << self.nloc) - 1))   # (an engine that knows its shard reports global bits)
     t = self.torch.tensor([p, float(self.rank)], dtype=self.torch.float64, device=self._red_device())
     allp = [self.torch.zeros_like(t) for _ in range(self.world)]
     self.dist.all_gather(allp, t)
@@ -498,7 +501,7 @@ class ShardedState:
       parts = [c.cpu() for c in cu]
     else:
       self.dist.all_gather(parts, mine)
-    phys = np.concatenate([p.numpy().view(np.complex128) for p in parts])
+    phys = np.concatenate([p.numpy().view(self.cdtype) for p in parts])
     idx = np.arange(1 << self.nbits, dtype=np.uint64)
     pidx = np.zeros_like(idx)
     for b in range(self.nbits):
@@ -535,3 +538,151 @@ class ShardedState:
   def close(self):
     self.eng.sync()
     self.eng.close()
+    if getattr(self.buf, 'is_cuda', False):
+      # hand the shard (up to 128 GiB) back to the driver: torch's caching allocator would keep it,
+      # and the engine's own hipMalloc calls in this process do not see torch's cache
+      self.buf = self._staging = None
+      self.torch.cuda.empty_cache()
+
+
+class ShardedDevice:
+  """The device-state interface `circuit.qc` drives (qcc_amd.device.DeviceState's), over a
+  ShardedState: with WORLD_SIZE > 1 every rank runs the same Python program (the reference's
+  algorithms are plain scripts: src/lib/circuit.py:68-101 and its callers) and each call below is
+  collective.  Readers return the same value on every rank.
+
+  Reference counterparts: state construction circuit.py:121-164, maxprob state.py:60-78,
+  measure_bit circuit.py:287-300 -- here as per-shard device reductions plus an 8-byte all-reduce."""
+
+  def __init__(self, nbits, bit_width=128, fusion=1, **kw):
+    self.st = ShardedState(nbits, fusion=fusion, bit_width=bit_width, **kw)
+    self.nbits, self.bit_width = int(nbits), int(bit_width)
+    self.dtype = self.st.cdtype
+    st = self.st
+    self._hip = hasattr(st.eng, 'lib')        # the real engine (device readers, init_product on the shard)
+    if self._hip:
+      st.eng.set_shard(st.nbits, st.rank)     # global bit positions for the engine's readers / product init
+
+  # -- helpers ---------------------------------------------------------------------
+  def _local_view(self):
+    """complex view [2^nloc] of the shard as a torch tensor (CPU stand-in engines only)."""
+    return self.st.torch.view_as_complex(self.st.buf.view(-1, 2))
+
+  def _all_sum(self, values):
+    st = self.st
+    t = st.torch.tensor([float(v) for v in values], dtype=st.torch.float64, device=st._red_device())
+    st.dist.all_reduce(t)
+    return [float(v) for v in t.tolist()]
+
+  def _reset_map(self):
+    self.st.eng.sync()
+    self.st.perm = list(range(self.st.nbits))
+
+  # -- initialisation / IO ---------------------------------------------------------
+  def init_basis(self, index=0):
+    self._reset_map()
+    self.st.init_basis(index)
+
+  def init_product(self, factors):
+    """Each rank builds ITS slice of f_0 (x) f_1 (x) ... in place (qh_init_product knows the shard)."""
+    st = self.st
+    self._reset_map()
+    if self._hip:
+      st.eng.init_product(factors)
+      return
+    idx = (np.uint64(st.rank) << np.uint64(st.nloc)) | np.arange(1 << st.nloc, dtype=np.uint64)
+    out = np.ones(idx.shape, dtype=np.complex128)
+    shift = st.nbits
+    for n, x in factors:
+      shift -= n
+      v = ((idx >> np.uint64(shift)) & np.uint64((1 << n) - 1)).astype(np.int64)
+      if isinstance(x, (int, np.integer)):
+        out *= (v == int(x))
+      else:
+        out *= np.asarray(x, dtype=np.complex128).reshape(-1)[v]
+    st.buf.copy_(st.torch.from_numpy(out.view(np.float64)))
+
+  def upload(self, host, offset=0):
+    assert offset == 0
+    st = self.st
+    self._reset_map()
+    a = np.ascontiguousarray(host, dtype=self.dtype).reshape(-1)
+    part = a[st.rank << st.nloc: (st.rank + 1) << st.nloc]
+    if self._hip:
+      st.eng.upload(part)
+    else:
+      st.buf.copy_(st.torch.from_numpy(part.view(np.float64 if self.bit_width == 128 else np.float32).copy()))
+
+  def download(self, offset=0, count=None, out=None):
+    full = self.st.gather_logical()
+    count = full.size - offset if count is None else count
+    return full[offset: offset + count]
+
+  # -- gates -------------------------------------------------------------------------
+  def apply1(self, gate, index):
+    self.st.apply1(gate, index)
+
+  def applyc(self, gate, control, target):
+    self.st.applyc(gate, control, target)
+
+  def run_stream(self, ops, gates8):
+    self.st.run_stream(ops, gates8)
+
+  def flush(self):
+    self.st.flush()
+
+  def sync(self):
+    self.st.sync()
+
+  # -- readers ---------------------------------------------------------------------
+  def norm2(self):
+    return self.st.norm2_global()
+
+  def argmax(self):
+    return self.st.argmax_global()
+
+  def amplitude(self, logical_index):
+    a = self.st.amplitude_local(logical_index)
+    re, im = self._all_sum([0.0, 0.0] if a is None else [a.real, a.imag])
+    return complex(re, im)
+
+  def prob_bit(self, logical_bit, value=1):
+    st = self.st
+    pb = st.perm[int(logical_bit)]
+    value = 1 if value else 0
+    if pb >= st.nloc:
+      p = st.eng.norm2() if ((st.rank >> (pb - st.nloc)) & 1) == value else 0.0
+    elif self._hip:
+      p = st.eng.prob_bit(pb, value)
+    else:
+      st.eng.sync()
+      v = self._local_view().view(-1, 2, 1 << pb)[:, value, :]
+      p = float((v.real ** 2 + v.imag ** 2).sum())
+    return self._all_sum([p])[0]
+
+  def project_bit(self, logical_bit, value):
+    st = self.st
+    pb = st.perm[int(logical_bit)]
+    value = 1 if value else 0
+    if pb >= st.nloc:
+      if ((st.rank >> (pb - st.nloc)) & 1) != value:
+        self.scale(0.0, _local=True)
+    elif self._hip:
+      st.eng.project_bit(pb, value)
+    else:
+      st.eng.sync()
+      self._local_view().view(-1, 2, 1 << pb)[:, 1 - value, :] = 0
+
+  def scale(self, z, _local=False):
+    st = self.st
+    if self._hip:
+      st.eng.scale(z)
+    else:
+      st.eng.sync()
+      self._local_view().mul_(complex(z))
+
+  def stats(self):
+    return self.st.stats()
+
+  def close(self):
+    self.st.close()

@@ -21,7 +21,10 @@ REF_TESTS = ['circuit_test', 'state_test', 'tensor_test', 'helper_test', 'measur
 ALGOS = ['arith_classic', 'arith_quantum', 'entanglement_swap', 'estimate_pi', 'hadamard_test',
          'hhl_2x2', 'inversion_test', 'pauli_rep', 'qram', 'quantum_mean', 'state_prep',
          'state_prep_mottonen', 'supremacy', 'counting', 'minimum_finding', 'teleportation',
-         'superdense', 'swap_test', 'phase_estimation']
+         'superdense', 'swap_test', 'phase_estimation',
+         # the rest of the qc-using algorithms
+         'grover', 'order_finding', 'sat3', 'hhl', 'graph_coloring', 'vqe_simple', 'quantum_walk', 'quantum_pca',
+         'hamiltonian_cycle']
 
 
 def _run(path, mode, env=None):

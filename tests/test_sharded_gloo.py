@@ -162,3 +162,114 @@ def _qft_only(rank, world, port, n, out_dir):
     np.savez(os.path.join(out_dir, 'qft.npz'), psi=full, exchanges=st.exchanges)
   dist.barrier()
   dist.destroy_process_group()
+
+
+# ---- circuit.qc() on a sharded register (north_star: "every algorithm runs unmodified") ----------
+def _grover_through_qc(nb, bits):
+  """grover.py:124-168 as the reference script writes it, through qcc_amd.lib.circuit.qc."""
+  import math
+  from qcc_amd.lib import circuit, ops
+  qc = circuit.qc('Grover')
+  reg = qc.reg(nb, 0)
+  qc.reg(1, 1)
+  aux = qc.reg(nb - 1, 0)
+  idx = list(range(nb))
+  qc.h(list(range(nb + 1)))
+  for _ in range(int(math.pi / 4 * math.sqrt(2 ** nb))):
+    for i in idx:
+      if bits[i] == 0:
+        qc.apply1(ops.PauliX(), i, 'x')
+    qc.multi_control(reg, nb, aux, ops.PauliX(), 'Phase Inversion')
+    for i in idx:
+      if bits[i] == 0:
+        qc.apply1(ops.PauliX(), i, 'x')
+    qc.h(idx); qc.x(idx)
+    qc.multi_control(reg, nb, aux, ops.PauliZ(), 'Mean Inversion')
+    qc.x(idx); qc.h(idx)
+  return qc
+
+
+def _qc_worker(rank, world, port, golden, out_dir):
+  os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                    LOCAL_RANK=str(rank))
+  import torch.distributed as dist
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  from qcc_amd import sharded
+  from qcc_amd.lib import backend, circuit, tensor
+  from tests import fake_device
+
+  def factory(nloc):
+    e = fake_device.NumpyShardEngine(nloc)
+    return e, e.buf
+  made = []
+
+  def device_factory(nbits, bw):
+    d = sharded.ShardedDevice(nbits, bw, engine_factory=factory, chunk_amps=64)
+    made.append(d)
+    return d
+  backend.set_device_factory(device_factory)
+  tensor.set_tensor_width(128)
+  g = np.load(golden)
+  bits = [int(b) for b in g['marked']]
+  qc = _grover_through_qc(len(bits), bits)
+  maxbits, maxprob = qc.maxprob()                     # per-shard arg-max + all-gather
+  n = qc.nbits
+  p_anc, _ = qc.measure_bit(len(bits), 1, collapse=False)      # ancilla qubit: local bit on every rank
+  p_top, _ = qc.measure_bit(0, bits[0], collapse=False)        # qubit 0: (originally) the shard bit
+  a_marked = qc.ampl(*(bits + [1] + [0] * (len(bits) - 1)))
+  psi = np.asarray(qc.psi).copy()
+  # collapse on a shard-resident qubit, then on a local one
+  p1, _ = qc.measure_bit(0, bits[0], collapse=True)
+  p2, _ = qc.measure_bit(n - 1, 0, collapse=True)
+  collapsed = np.asarray(qc.psi).copy()
+  # a second register built as a product state on the shards (superposed factor on the shard bit)
+  qc2 = circuit.qc('prod')
+  qc2.qubit(0.6, 0.8)
+  qc2.reg(5, 0b10110)
+  qc2.qubit(1 / np.sqrt(2), 1j / np.sqrt(2))
+  qc2.cx(0, 3)
+  qc2.h(6)
+  psi2 = np.asarray(qc2.psi).copy()
+  if rank == 0:
+    np.savez(os.path.join(out_dir, 'qc.npz'), psi=psi, maxbits=np.array(maxbits), maxprob=maxprob, p_anc=p_anc, p_top=p_top,
+             a_marked=a_marked, p1=p1, p2=p2, collapsed=collapsed, psi2=psi2, exchanges=made[0].st.exchanges,
+             sharded=len(made))
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 4])
+def test_qc_api_runs_on_a_sharded_register(oracle, golden_dir, tmp_path, world):
+  """The reference's Grover script (nbits=6, 12 qubits) through circuit.qc() with the register sharded
+  over 2 / 4 ranks: final state equals the reference's recorded state (g5_grover6.npz); maxprob,
+  measure_bit (probability and collapse, on shard and local qubits), ampl and device-side product
+  registers agree with a single-process run."""
+  golden = os.path.join(golden_dir, 'g5_grover6.npz')
+  port = _free_port()
+  mp.spawn(_qc_worker, args=(world, port, golden, str(tmp_path)), nprocs=world, join=True)
+  res = np.load(tmp_path / 'qc.npz')
+  g = np.load(golden)
+  want = g['final']
+  bits = [int(b) for b in g['marked']]
+  nb, n = len(bits), int(g['nbits'])
+  assert int(res['sharded']) == 2 and int(res['exchanges']) >= 1
+  assert np.max(np.abs(res['psi'] - want)) < 1e-10
+  assert res['maxbits'][:nb].tolist() == bits
+  p = np.abs(want) ** 2
+  idx = np.arange(1 << n)
+  assert abs(float(res['maxprob']) - p.max()) < 1e-12
+  assert abs(float(res['p_anc']) - p[((idx >> (n - 1 - nb)) & 1) == 1].sum()) < 1e-12
+  assert abs(float(res['p_top']) - p[((idx >> (n - 1)) & 1) == bits[0]].sum()) < 1e-12
+  marked_index = int(''.join(map(str, bits + [1] + [0] * (nb - 1))), 2)
+  assert abs(complex(res['a_marked']) - want[marked_index]) < 1e-12
+  c = want.copy()
+  c[((idx >> (n - 1)) & 1) != bits[0]] = 0
+  c /= np.sqrt(float(res['p1']))
+  c[(idx & 1) != 0] = 0
+  c /= np.sqrt(float(res['p2']))
+  assert np.max(np.abs(res['collapsed'] - c)) < 1e-10
+  # the product register: kron of the factors, then cx(0,3), h(6)
+  v = np.kron(np.kron(np.array([0.6, 0.8]), np.eye(32)[0b10110]), np.array([1, 1j]) / np.sqrt(2)).astype(np.complex128)
+  oracle.applyc(v, np.array([0, 1, 1, 0], dtype=np.complex128), 7, 0, 3)
+  oracle.apply1(v, np.array([1, 1, 1, -1], dtype=np.complex128) / np.sqrt(2), 7, 6)
+  assert np.max(np.abs(res['psi2'] - v)) < 1e-12
