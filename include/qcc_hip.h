@@ -82,6 +82,9 @@ int qh_destroy(qh_handle h);
  * index has high bits == shard_index, out of a 2^nbits_global state.  Gates
  * are then addressed in GLOBAL qubit numbers / bit positions.               */
 int qh_set_shard(qh_handle h, int nbits_global, uint64_t shard_index);
+/* Device pointer of the shard, amplitudes in physical order.  A handle that owns its memory may
+ * re-lay the state out between two buffers while sweeps run (planner.h, relayout): this call
+ * brings it back to canonical order first and the pointer is valid until the next gate.      */
 int qh_device_ptr(qh_handle h, void **ptr);
 int qh_stream(qh_handle h, void **stream);
 int qh_nbits(qh_handle h, int *nbits_local, int *nbits_global);
@@ -184,6 +187,9 @@ int qh_comm_allreduce_sum(qh_handle h, double *inout, int count);
 
 /* ---- device-side readers (state.py:24-78) ------------------ */
 int qh_norm2(qh_handle h, double *out);                       /* sum |a|^2 of the shard */
+/* One amplitude by LOGICAL index (state.py:31-40 ampl/prob), read where it lives now: no
+ * re-layout, 16 bytes over PCIe.  QH_ERR_NONLOCAL if another shard holds it.                */
+int qh_amplitude(qh_handle h, uint64_t logical_index, double out[2]);
 int qh_argmax(qh_handle h, uint64_t *phys_index, double *prob); /* max |a|^2 of the shard */
 int qh_prob_bit(qh_handle h, int logical_bit, double *p1);    /* sum |a|^2 with bit set (shard) */
 int qh_prob_bit_value(qh_handle h, int logical_bit, int value, double *p); /* ... with bit == value */
@@ -210,9 +216,11 @@ int qh_timer_end(qh_handle h, float *milliseconds);
 int qh_plan_json(qh_handle h, char *buf, uint64_t cap, uint64_t *needed);
 
 /* The same plan in binary form, complete (ops, phase groups, tables): 3 x u64 (magic
- * 0x51485031, sweeps, gates dropped as no-ops), then per sweep 26 x i64 (rb, regpos[5],
+ * 0x51485032, sweeps, gates dropped as no-ops), 64 bytes final_pos (position after the flush of
+ * the index bit at each position before it), then per sweep 26 x i64 (rb, regpos[5],
  * regpos_store[5], lanehi[3], nwave, wavepos[2], fixed_ones, ntiles, #ops, #groups, #oterms,
- * #table doubles, #lane tables, lane_low, 0) followed by the SweepOp / DGroup / OTerm / table arrays of
+ * #table doubles, #lane tables, lane_low, relayout), 64 bytes dest_pos, 5 x i64 (lanehi and wavepos
+ * at store time), followed by the SweepOp / DGroup / OTerm / table arrays of
  * qcc_amd/csrc/planner.h, each padded to 8 bytes.  For tools and tests that check a plan
  * without a GPU (tests/plan_interp.py executes it with NumPy).                 */
 int qh_plan_export(qh_handle h, void *buf, uint64_t cap, uint64_t *needed);
@@ -224,6 +232,9 @@ int qh_host_apply1(void *psi, const double gate[8], int nbits, int tgt,
                    int bit_width);
 int qh_host_applyc(void *psi, const double gate[8], int nbits, int ctl, int tgt,
                    int bit_width);
+/* The two calls above keep device scratch per calling thread (the two most recent register
+ * shapes); this frees the calling thread's.  Safe to call at any time, from any thread.       */
+int qh_host_release(void);
 
 #ifdef __cplusplus
 }

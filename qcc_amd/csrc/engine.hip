@@ -53,6 +53,8 @@ struct qh_state_s {
   int nloc = 0, nglob = 0, bw = 128, device = 0;
   uint64_t shard = 0;
   void *d_psi = nullptr;
+  void *d_alt = nullptr;       // second buffer of the same size: target of relayout sweeps (lazily allocated)
+  int relayout = -1;           // -1 undecided, 0 off (attached memory, no room, QH_RELAYOUT=0), 1 on
   bool owns_mem = false, owns_stream = false, dry = false;
   hipStream_t stream = nullptr;
   int fusion = QH_FUSE_OFF;
@@ -267,6 +269,61 @@ int use_device(qh_state_s *h) {
   return QH_OK;
 }
 
+// Sweeps may re-lay the state out into a second buffer (planner.h, Planner::relayout) when the
+// handle owns its memory, takes part in no exchange, and a second buffer of the same size fits.
+bool relayout_ready(qh_state_s *h) {
+  if (h->dry) return env_int("QH_RELAYOUT", 1) != 0;      // planner-only handles: plan what a real handle would
+  if (h->relayout < 0) {
+    h->relayout = 0;
+    if (env_int("QH_RELAYOUT", 1) != 0 && h->owns_mem && !h->comm && qh::sweep_supported(h->nloc, h->bw)) {
+      const size_t bytes = (size_t)h->amp_bytes() << h->nloc;
+      size_t fr = 0, total = 0;
+      if (hipMemGetInfo(&fr, &total) == hipSuccess && fr > bytes + (bytes >> 4) + (1ull << 30) &&
+          hipMalloc(&h->d_alt, bytes) == hipSuccess)
+        h->relayout = 1;
+      else
+        (void)hipGetLastError();
+    }
+  }
+  return h->relayout == 1 && !h->comm;
+}
+
+bool layout_is_canonical(const qh_state_s *h) {
+  int last = -1;
+  for (int b = 0; b < h->nglob; ++b) {
+    if (h->perm[b] >= h->nloc) continue;
+    if (h->perm[b] < last) return false;
+    last = h->perm[b];
+  }
+  return true;
+}
+
+// Brings the local index bits back into ascending logical order (one gather pass into the second
+// buffer): for the entry points that hand out or take amplitudes in physical order.
+int canonicalize(qh_state_s *h) {
+  if (h->dry || layout_is_canonical(h)) return QH_OK;
+  if (!h->d_alt) return fail(QH_ERR_ARG, "internal: permuted layout without a second buffer");
+  std::vector<int> loc;                       // logical bits that live on local positions, ascending
+  for (int b = 0; b < h->nglob; ++b) if (h->perm[b] < h->nloc) loc.push_back(b);
+  std::vector<int> posn;                      // the local positions they occupy, ascending
+  for (int b : loc) posn.push_back(h->perm[b]);
+  std::sort(posn.begin(), posn.end());
+  qh::BitPerm bp{};
+  bp.n = h->nloc;
+  for (size_t k = 0; k < loc.size(); ++k) bp.src_of_dst[posn[k]] = (uint8_t)h->perm[loc[k]];
+  const uint64_t n = 1ull << h->nloc;
+  const unsigned grid = (unsigned)std::min<uint64_t>((n + 255) / 256, 1ull << 22);
+  if (h->bw == 128)
+    hipLaunchKernelGGL(qh::k_permute_bits<double>, dim3(grid), dim3(256), 0, h->stream, (const double2 *)h->d_psi, (double2 *)h->d_alt, n, bp);
+  else
+    hipLaunchKernelGGL(qh::k_permute_bits<float>, dim3(grid), dim3(256), 0, h->stream, (const float2 *)h->d_psi, (float2 *)h->d_alt, n, bp);
+  int rc = check_launch(h);
+  if (rc) return rc;
+  std::swap(h->d_psi, h->d_alt);
+  for (size_t k = 0; k < loc.size(); ++k) h->perm[loc[k]] = posn[k];
+  return QH_OK;
+}
+
 // Runs the queue.  On failure the gates that did NOT run stay queued (qh_pending_gates):
 // a planning / allocation failure keeps the whole queue, a failed per-gate launch keeps the
 // failing gate and everything after it.  Only a failed launch of a planned sweep leaves the
@@ -285,8 +342,16 @@ int flush_impl(qh_state_s *h, qh::SlabIO *split = nullptr) {
     qh::SlabIO *io = split ? split : &local;
     io->arrivals = arr;
     io->comm = h->comm;
+    const bool relay = !split && relayout_ready(h);
+    void *result = h->d_psi;
+    uint8_t final_pos[64];
     rc = qh::run_fused(h->queue, h->nloc, h->shard, h->bw, h->d_psi, h->stream, h->dry,
-                       &h->sweep, &h->stats, &g_err, h->comm ? io : nullptr);
+                       &h->sweep, &h->stats, &g_err, h->comm ? io : nullptr, h->d_alt, relay, &result, final_pos);
+    if (rc == QH_OK && relay) {
+      if (result != h->d_psi) std::swap(h->d_psi, h->d_alt);
+      for (int b = 0; b < h->nglob; ++b)
+        if (h->perm[b] < h->nloc) h->perm[b] = final_pos[h->perm[b]];
+    }
     if (!h->dry) qh::wait_all_arrivals(arr, h->stream);   // (a flush that planned no sweep)
     if (h->comm) h->comm->stats.sweeps_overlapped += io->sweeps_overlapped;
     if (rc != QH_OK && h->stats.kernels_launched == launched0) return rc;   // nothing ran: queue kept
@@ -495,6 +560,7 @@ int qh_destroy(qh_handle h) {
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->owns_mem && h->d_psi) (void)hipFree(h->d_psi);
+    if (h->d_alt) (void)hipFree(h->d_alt);
     if (h->owns_stream && h->stream) (void)hipStreamDestroy(h->stream);
   }
   delete h;
@@ -515,6 +581,11 @@ int qh_set_shard(qh_handle h, int nbits_global, uint64_t shard_index) {
 
 int qh_device_ptr(qh_handle h, void **ptr) {
   if (!h || !ptr) return fail(QH_ERR_ARG, "null");
+  if (!h->dry && !layout_is_canonical(h)) {   // the caller reads amplitudes in physical order
+    int rc = flush_impl(h);
+    if (rc == QH_OK) rc = canonicalize(h);
+    if (rc) return rc;
+  }
   *ptr = h->d_psi;
   return QH_OK;
 }
@@ -653,6 +724,7 @@ int qh_upload(qh_handle h, const void *host, uint64_t offset, uint64_t count) {
   if (offset + count > (1ull << h->nloc)) return fail(QH_ERR_ARG, "upload range out of bounds");
   HIP_TRY(hipSetDevice(h->device));
   int rc = flush_impl(h);
+  if (rc == QH_OK) rc = canonicalize(h);
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync((char *)h->d_psi + offset * h->amp_bytes(), host, count * h->amp_bytes(),
                          hipMemcpyHostToDevice, h->stream));
@@ -665,10 +737,34 @@ int qh_download(qh_handle h, void *host, uint64_t offset, uint64_t count) {
   if (offset + count > (1ull << h->nloc)) return fail(QH_ERR_ARG, "download range out of bounds");
   HIP_TRY(hipSetDevice(h->device));
   int rc = flush_impl(h);
+  if (rc == QH_OK) rc = canonicalize(h);
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(host, (const char *)h->d_psi + offset * h->amp_bytes(),
                          count * h->amp_bytes(), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
+  return QH_OK;
+}
+
+int qh_amplitude(qh_handle h, uint64_t logical_index, double out[2]) {
+  if (!h || !out || h->dry) return fail(QH_ERR_ARG, "null/dry");
+  if (h->nglob < 64 && (logical_index >> h->nglob)) return fail(QH_ERR_ARG, "index out of range");
+  HIP_TRY(hipSetDevice(h->device));
+  int rc = flush_impl(h);
+  if (rc) return rc;
+  uint64_t phys;
+  qh_logical_to_phys(h, logical_index, &phys);
+  if ((phys >> h->nloc) != h->shard) return fail(QH_ERR_NONLOCAL, "amplitude %llu lives on shard %llu", (unsigned long long)logical_index, (unsigned long long)(phys >> h->nloc));
+  const uint64_t li = phys & h->local_mask();
+  if (h->bw == 128) {
+    HIP_TRY(hipMemcpyAsync(out, (const char *)h->d_psi + li * 16, 16, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  } else {
+    float f[2];
+    HIP_TRY(hipMemcpyAsync(f, (const char *)h->d_psi + li * 8, 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    out[0] = f[0];
+    out[1] = f[1];
+  }
   return QH_OK;
 }
 
@@ -892,7 +988,7 @@ int qh_timer_end(qh_handle h, float *ms) {
 int qh_plan_json(qh_handle h, char *buf, uint64_t cap, uint64_t *needed) {
   if (!h) return fail(QH_ERR_ARG, "null");
   std::string s = qh::plan_to_json(h->queue, h->nloc, h->shard, h->bw, qh::sweep_max_rb(),
-                                   qh::sweep_split_lanes());
+                                   qh::sweep_split_lanes(), relayout_ready(h));
   if (needed) *needed = s.size() + 1;
   if (buf && cap) {
     const uint64_t n = std::min<uint64_t>(cap - 1, s.size());
@@ -906,16 +1002,17 @@ int qh_plan_export(qh_handle h, void *buf, uint64_t cap, uint64_t *needed) {
   if (!h) return fail(QH_ERR_ARG, "null");
   if (!qh::sweep_supported(h->nloc, h->bw)) return fail(QH_ERR_ARG, "state too small for sweeps");
   qh::PlanResult pr = qh::plan_best(h->queue, h->nloc, h->shard, h->bw, qh::sweep_max_rb(),
-                                    qh::sweep_split_lanes());
+                                    qh::sweep_split_lanes(), relayout_ready(h));
   std::vector<uint64_t> out;
   auto put_bytes = [&](const void *p, size_t n) {
     const size_t w = (n + 7) / 8, at = out.size();
     out.resize(at + w, 0);
     if (n) memcpy(&out[at], p, n);
   };
-  out.push_back(0x51485031ull);
+  out.push_back(0x51485032ull);
   out.push_back(pr.sweeps.size());
   out.push_back(pr.noop_gates);
+  put_bytes(pr.final_pos, 64);
   for (auto &sp : pr.sweeps) {
     int64_t hdr[26] = {0};
     int k = 0;
@@ -933,7 +1030,13 @@ int qh_plan_export(qh_handle h, void *buf, uint64_t cap, uint64_t *needed) {
     hdr[k++] = (int64_t)sp.tables.size();
     hdr[k++] = sp.n_ltab;
     hdr[k++] = sp.lane_low;
+    hdr[k++] = sp.relayout ? 1 : 0;
     put_bytes(hdr, sizeof hdr);
+    put_bytes(sp.dest_pos, 64);
+    {
+      int64_t st[5] = {sp.lanehi_store[0], sp.lanehi_store[1], sp.lanehi_store[2], sp.wavepos_store[0], sp.wavepos_store[1]};
+      put_bytes(st, sizeof st);
+    }
     put_bytes(sp.ops.data(), sp.ops.size() * sizeof(qh::SweepOp));
     put_bytes(sp.groups.data(), sp.groups.size() * sizeof(qh::DGroup));
     put_bytes(sp.oterms.data(), sp.oterms.size() * sizeof(qh::OTerm));
@@ -1261,18 +1364,46 @@ int qh_comm_allreduce_sum(qh_handle h, double *inout, int count) {
 extern "C" {
 
 // ---- literal drop-in on host buffers ------------------------------------------
-static qh_handle g_host_h = nullptr;
+// The device-side scratch of qh_host_apply1/applyc: per calling THREAD (the boundary is "one host
+// thread per handle"), the two most recently used (nbits, width) shapes are kept so that an
+// algorithm alternating between two register sizes does not pay a hipMalloc/hipFree pair per gate.
+// qh_host_release() frees the calling thread's scratch; threads that exit without calling it leak
+// nothing but address space until process exit (the handles are owned by the thread_local object).
+namespace {
+struct HostScratch {
+  qh_handle slot[2] = {nullptr, nullptr};
+  ~HostScratch() {
+    for (qh_handle &h : slot) {
+      if (h) qh_destroy(h);
+      h = nullptr;
+    }
+  }
+};
+thread_local HostScratch g_host;
+}  // namespace
 
 static int host_handle(int nbits, int bw, qh_handle *out) {
-  if (g_host_h && (g_host_h->nloc != nbits || g_host_h->bw != bw)) {
-    qh_destroy(g_host_h);
-    g_host_h = nullptr;
+  for (int k = 0; k < 2; ++k)
+    if (g_host.slot[k] && g_host.slot[k]->nloc == nbits && g_host.slot[k]->bw == bw) {
+      if (k == 1) std::swap(g_host.slot[0], g_host.slot[1]);   // most recent first
+      *out = g_host.slot[0];
+      return QH_OK;
+    }
+  if (g_host.slot[1]) qh_destroy(g_host.slot[1]);
+  g_host.slot[1] = g_host.slot[0];
+  g_host.slot[0] = nullptr;
+  int rc = qh_create(nbits, bw, 0, &g_host.slot[0]);
+  if (rc) return rc;
+  g_host.slot[0]->relayout = 0;   // one gate per call: nothing to gain from a second buffer
+  *out = g_host.slot[0];
+  return QH_OK;
+}
+
+int qh_host_release(void) {
+  for (qh_handle &h : g_host.slot) {
+    if (h) qh_destroy(h);
+    h = nullptr;
   }
-  if (!g_host_h) {
-    int rc = qh_create(nbits, bw, 0, &g_host_h);
-    if (rc) return rc;
-  }
-  *out = g_host_h;
   return QH_OK;
 }
 

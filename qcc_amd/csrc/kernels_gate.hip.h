@@ -220,6 +220,24 @@ __global__ __launch_bounds__(256) void k_init_product(typename AmpT<R>::type *__
   }
 }
 
+// Out-of-place permutation of the index bits: dst[i] = src[P(i)], bit p of i supplying bit
+// src_of_dst[p] of P(i).  Relayout sweeps never move the low line bits, so neighbouring lanes
+// still read whole 128-byte lines.  Used to bring a re-laid-out state back to canonical order
+// before amplitudes are handed out in physical order (download, device pointer).
+struct BitPerm {
+  int n;
+  uint8_t src_of_dst[64];
+};
+template <typename R>
+__global__ __launch_bounds__(256) void k_permute_bits(const typename AmpT<R>::type *__restrict__ src,
+                                                      typename AmpT<R>::type *__restrict__ dst, uint64_t n, BitPerm bp) {
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+    uint64_t j = 0;
+    for (int p = 0; p < bp.n; ++p) j |= ((i >> p) & 1ull) << bp.src_of_dst[p];
+    st_amp<true>(dst + i, ld_amp<true>(src + j));
+  }
+}
+
 // ---- readers ----------------------------------------------------
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

@@ -141,6 +141,16 @@ struct SweepPlan {
   int wavepos[kMaxWaveBits] = {0}; // these index bits; a gate on one runs after OP_WSWAP moved it into registers
   uint64_t fixed_ones = 0;         // local bits fixed to 1 in the tile enumeration
   uint64_t ntiles = 0;             // wavefront tiles to process
+  // RELAYOUT (out-of-place "gather" sweep): the tile is loaded from wherever its bits are and
+  // stored CONTIGUOUSLY into the handle's second buffer -- lane bits on positions 0..5, register
+  // bit k on 6+k, wave bit j on 6+rb+j, every other index bit above, order kept.  dest_pos[p] =
+  // new position of the index bit at position p (local bits only).  See Planner::relayout().
+  bool relayout = false;
+  uint8_t dest_pos[64] = {0};
+  int lanehi_store[kLaneHi] = {3, 4, 5};   // index bits the movable lane bits / wave bits hold when the
+  int wavepos_store[kMaxWaveBits] = {0};   // tile is stored (only a relayout sweep may leave them exchanged)
+  int reg_dest[kMaxRegBits] = {6, 7, 8, 9, 10};  // relayout: where register bit k / wave bit j go (positions 6.. of the
+  int wave_dest[kMaxWaveBits] = {11, 12};        // contiguous block, in ascending order of the index bits they hold)
   std::vector<SweepOp> ops;
   std::vector<DGroup> groups;
   std::vector<OTerm> oterms;
@@ -156,6 +166,9 @@ struct SweepPlan {
 struct PlanResult {
   std::vector<SweepPlan> sweeps;
   uint64_t noop_gates = 0;  // dropped: shard-bit control unsatisfied / identity
+  bool moved = false;       // some sweep re-laid the state out:
+  uint8_t final_pos[64];    // position, after the flush, of the index bit that was at position p before it
+  PlanResult() { for (int p = 0; p < 64; ++p) final_pos[p] = (uint8_t)p; }
 };
 
 inline int popc(uint64_t x) { return __builtin_popcountll(x); }
@@ -170,10 +183,37 @@ inline uint64_t gate_alg_bytes(const GateRec &r, int nloc, uint64_t amp_bytes) {
   return touched * amp_bytes * 2;
 }
 
+// A relayout sweep writes unit w (tile / super-tile number: the index bits outside the tile, in
+// ascending order) to block P(w) of the second buffer, P = the bit permutation dest_pos induces on
+// those bits.  P is handed to the kernel as runs of bits that move together: dst |= shift(w & mask).
+constexpr int kMaxUnitSegs = 8;
+inline int unit_segments(const SweepPlan &sp, int nloc, uint64_t *masks, int *shifts) {
+  uint64_t tile = (1ull << sp.lane_low) - 1;
+  for (int k = 0; k < sp.nlanehi(); ++k) tile |= 1ull << sp.lanehi_store[k];
+  for (int k = 0; k < sp.rb; ++k) tile |= 1ull << sp.regpos_store[k];
+  for (int k = 0; k < sp.nwave; ++k) tile |= 1ull << sp.wavepos_store[k];
+  const int tilebits = popc(tile);
+  int nseg = 0, i = 0, last_shift = 1 << 20;
+  for (int p = 0; p < nloc; ++p) {
+    if ((tile >> p) & 1ull) continue;
+    const int shift = ((int)sp.dest_pos[p] - tilebits) - i;   // unit bit i moves to unit bit i + shift
+    if (shift != last_shift) {
+      ++nseg;
+      last_shift = shift;
+      if (masks && nseg <= kMaxUnitSegs) { masks[nseg - 1] = 0; shifts[nseg - 1] = shift; }
+    }
+    if (masks && nseg <= kMaxUnitSegs) masks[nseg - 1] |= 1ull << i;
+    ++i;
+  }
+  return nseg;
+}
+
 class Planner {
  public:
-  Planner(int nloc, uint64_t shard, int bw, int max_rb, bool split_lanes = true, int wave_bits = -1)
-      : nloc_(nloc), shard_(shard), amp_bytes_(bw == 128 ? 16 : 8), split_lanes_(split_lanes) {
+  Planner(int nloc, uint64_t shard, int bw, int max_rb, bool split_lanes = true, int wave_bits = -1,
+          bool allow_relayout = false)
+      : nloc_(nloc), shard_(shard), amp_bytes_(bw == 128 ? 16 : 8), split_lanes_(split_lanes),
+        relayout_(allow_relayout) {
     rb_cap_ = std::min({max_rb, kMaxRegBits, nloc - kLaneBits});
     lane_low_ = bw == 128 ? 3 : 4;   // 128-byte lines: 8 complex128 or 16 complex64 amplitudes
     lane_hi_ = kLaneBits - lane_low_;
@@ -218,6 +258,7 @@ class Planner {
     }
     std::vector<uint64_t> alg = alg_override_;
     std::vector<uint32_t> weight(pending.size(), 1);
+    std::vector<int> first_tile;
     fuse_sleator_weinfurter(&pending, &alg, &weight);
     if (propagate_x_) propagate_x(&pending, &alg, &weight, &out.noop_gates);
     weight_.swap(weight);
@@ -226,6 +267,41 @@ class Planner {
       std::vector<uint64_t> rest_alg;
       std::vector<uint32_t> rest_w;
       out.sweeps.push_back(build_sweep(pending, alg, &rest, &rest_alg, &rest_w));
+      if (out.sweeps.size() == 1) {     // where this flush began: see the last sweep below
+        const SweepPlan &f = out.sweeps[0];
+        for (int k = 0; k < f.nlanehi(); ++k) first_tile.push_back(f.lanehi[k]);
+        for (int k = 0; k < f.rb; ++k) first_tile.push_back(f.regpos[k]);
+        for (int k = 0; k < f.nwave; ++k) first_tile.push_back(f.wavepos[k]);
+      }
+      if (out.sweeps.back().relayout) {
+        std::vector<int> ahead;
+        if (!rest.empty()) {
+          select_tile_bits(rest, &ahead);
+        } else if (out.sweeps.size() > 1) {
+          // last sweep of the flush: nothing is known about what comes next; circuits run in loops
+          // (Grover iterations, the QFT of every bench step), so bet on the bits this flush started with
+          for (int p : first_tile) ahead.push_back(out.final_pos[p]);
+        }
+        std::sort(ahead.begin(), ahead.end());
+        finish_relayout(&out.sweeps.back(), ahead);
+        if (unit_segments(out.sweeps.back(), nloc_, nullptr, nullptr) > kMaxUnitSegs)
+          finish_relayout(&out.sweeps.back(), std::vector<int>());   // (the kernel moves at most 8 runs of unit-index bits)
+      }
+      const SweepPlan &done = out.sweeps.back();
+      if (done.relayout) {      // the gates still to come live in the new layout
+        auto map_mask = [&](uint64_t m) {
+          uint64_t o = m >> nloc_ << nloc_;
+          for (uint64_t t = m & lm; t; t &= t - 1) o |= 1ull << done.dest_pos[__builtin_ctzll(t)];
+          return o;
+        };
+        for (GateRec &r : rest) {
+          r.ctl_mask = map_mask(r.ctl_mask);
+          r.neg_mask = map_mask(r.neg_mask);
+          if (r.tgt >= 0 && r.tgt < nloc_) r.tgt = done.dest_pos[r.tgt];
+        }
+        for (int p = 0; p < nloc_; ++p) out.final_pos[p] = done.dest_pos[out.final_pos[p]];
+        out.moved = true;
+      }
       pending.swap(rest);
       alg.swap(rest_alg);
       weight_.swap(rest_w);
@@ -240,6 +316,7 @@ class Planner {
   int rb_cap_;
   int lane_low_ = kLaneLow, lane_hi_ = kLaneHi;
   bool split_lanes_;   // allow lane bits 3..5 to sit on arbitrary index bits (8 free tile bits)
+  bool relayout_;      // sweeps may store into the second buffer with the tile bits moved to the low positions
   bool butterflies_ = env_flag("QH_BFLY", true);        // unit-entry butterfly ops (emit_ops_with)
   size_t dense_weight_ = env_int("QH_PLAN_DENSE_W", 1);  // score of a dense gate when choosing tile bits (diagonal = 1)
   // wave bits per tile (see plan_best): QH_WAVE_BITS pins it
@@ -251,6 +328,7 @@ class Planner {
   int min_table_terms_ = env_int("QH_MIN_TABLE_TERMS", 2);
   int lane_valu_ = env_int("QH_LANE_VALU", 1);          // 0 never, 1 by cost model (choose_lane_paths), 2 always (tests)
   bool defer_diag_ = env_flag("QH_DEFER_DIAG", true);   // see build_sweep
+  bool lookahead_ = env_flag("QH_RELAYOUT_AHEAD", true); // see finish_relayout
   std::vector<uint64_t> alg_override_;
   std::vector<uint32_t> weight_;  // reference gate applications each pending record stands for
 
@@ -503,15 +581,7 @@ class Planner {
     return m;
   }
 
-  // Choose the tile bits of a sweep greedily by SIMULATION: add, one at a time, the
-  // candidate bit that lets the most queued gates run in this sweep (first-come
-  // order breaks ties).  For a QFT this reproduces "the next target bits in order";
-  // for layered circuits (supremacy, Grover ladders) it picks qubits whose gates
-  // unblock each other instead of the first ones that happen to come up.
-  SweepPlan build_sweep(const std::vector<GateRec> &pending, const std::vector<uint64_t> &alg,
-                        std::vector<GateRec> *rest, std::vector<uint64_t> *rest_alg,
-                        std::vector<uint32_t> *rest_w) {
-    SweepPlan sp;
+  void select_tile_bits(const std::vector<GateRec> &pending, std::vector<int> *sel_out) const {
     const size_t window = std::min<size_t>(pending.size(), 4096);
     const uint64_t always = (1ull << lane_low_) - 1;
     std::vector<int> cand;       // dense target bits above bit 2, in order of first use
@@ -521,7 +591,7 @@ class Planner {
           std::find(cand.begin(), cand.end(), r.tgt) == cand.end())
         cand.push_back(r.tgt);
     }
-    std::vector<int> sel, lanehi, regs, waves;
+    std::vector<int> sel;
     size_t best_total = pass(pending, always, window, nullptr);
     while ((int)sel.size() < lane_hi_ + rb_cap_ + max_wave_) {
       int best_bit = -1;
@@ -538,6 +608,21 @@ class Planner {
       sel.push_back(best_bit);
       best_total = best;
     }
+    sel_out->swap(sel);
+  }
+
+  // Choose the tile bits of a sweep greedily by SIMULATION: add, one at a time, the
+  // candidate bit that lets the most queued gates run in this sweep (first-come
+  // order breaks ties).  For a QFT this reproduces "the next target bits in order";
+  // for layered circuits (supremacy, Grover ladders) it picks qubits whose gates
+  // unblock each other instead of the first ones that happen to come up.
+  SweepPlan build_sweep(const std::vector<GateRec> &pending, const std::vector<uint64_t> &alg,
+                        std::vector<GateRec> *rest, std::vector<uint64_t> *rest_alg,
+                        std::vector<uint32_t> *rest_w) {
+    SweepPlan sp;
+    const uint64_t always = (1ull << lane_low_) - 1;
+    std::vector<int> sel, lanehi, regs, waves;
+    select_tile_bits(pending, &sel);
     assign_bits(sel, &lanehi, &regs, &waves);
     uint64_t regmask = mask_of(regs);
     uint64_t lanemask = always | mask_of(lanehi);
@@ -1020,12 +1105,18 @@ class Planner {
     // offsets, base corrected by the moved index bits) -- one LDS exchange less per wave bit.
     // (only for tiles with contiguous lanes: with split lanes the exchanged layout is the
     // slower store geometry -- 7.1 vs 6.75 ms on sweep 2 of the QFT -- and undoing wins)
-    if (store_swapped_ && sp->contiguous()) {
+    // A RELAYOUT sweep stores the tile contiguously into the second buffer whatever its bits are
+    // now: neither kind of exchange is undone (see relayout()).
+    if (want_relayout(*sp)) {
+      sp->relayout = true;      // (dest_pos: plan() -> finish_relayout, once the next sweep's targets are known)
+    } else if (store_swapped_ && sp->contiguous()) {
       while (!swaps.empty() && !swaps.back().wave) { lswap(swaps.back().idx, swaps.back().r); swaps.pop_back(); }
     } else {
       restore_layout();
     }
     memcpy(sp->regpos_store, geom.regpos, sizeof geom.regpos);
+    memcpy(sp->lanehi_store, geom.lanehi, sizeof geom.lanehi);
+    memcpy(sp->wavepos_store, geom.wavepos, sizeof geom.wavepos);
     // lane tables go to the front of `tables` (one contiguous block: the kernel copies it to LDS)
     const uint32_t nlt = (uint32_t)(sp->ltabs.size() / 2);
     if (nlt) {
@@ -1035,6 +1126,51 @@ class Planner {
       sp->ltabs.clear();
     }
     sp->n_ltab = (int)(nlt / 64);
+  }
+
+  // A sweep whose tile does not sit on the low index bits reads eight 128-byte lines per load
+  // instruction (split lanes) and rewrites the same scattered lines: 6.2-7.1 ms per 2 x 16 GiB
+  // against 5.2 ms for a contiguous tile (profiles/r02: the lines of a wave are 64 KiB - 32 MiB
+  // apart; with tile bits >= 21 a third of the L1 translation requests miss).  Measured with the
+  // same tiles (tools/membench/oopsweep): scattered load + CONTIGUOUS store into a second buffer
+  // runs 15-20% faster than the in-place sweep, so a sweep that touches every amplitude anyway
+  // may as well leave its tile bits on the low positions -- where they stay for the next flush.
+  bool want_relayout(const SweepPlan &sp) const {
+    if (!relayout_ || sp.fixed_ones) return false;      // (a sweep that skips amplitudes cannot move the rest)
+    const int low = sp.lane_low;
+    for (int k = 0; k < sp.nlanehi(); ++k) if (sp.lanehi[k] != low + k) return true;
+    for (int k = 0; k < sp.rb; ++k) if (sp.regpos[k] != kLaneBits + k) return true;
+    for (int k = 0; k < sp.nwave; ++k) if (sp.wavepos[k] != kLaneBits + sp.rb + k) return true;
+    return false;                                       // already contiguous: in place
+  }
+
+  // The store map of a relayout sweep: its own tile bits (as they sit at store time) on the low
+  // positions; directly above them the bits the NEXT sweep will want as dense targets (`ahead`,
+  // N3 "qubit remapping to keep hot targets in low bits": a gather from lines 64 KiB - 16 MiB apart
+  // runs at 5.8 ms per 2 x 16 GiB, from lines >= 32 MiB apart at 6.5-6.9); the rest above, order kept.
+  void finish_relayout(SweepPlan *sp, const std::vector<int> &ahead) const {
+    uint64_t placed = (1ull << sp->lane_low) - 1;
+    for (int p = 0; p < sp->lane_low; ++p) sp->dest_pos[p] = (uint8_t)p;
+    int next = sp->lane_low;
+    auto put = [&](int p) {
+      if (p < 0 || p >= nloc_ || ((placed >> p) & 1ull)) return;
+      sp->dest_pos[p] = (uint8_t)next++;
+      placed |= 1ull << p;
+    };
+    for (int k = 0; k < sp->nlanehi(); ++k) put(sp->lanehi_store[k]);
+    // register and wave bits share the positions above the lanes, sorted by the index bits they hold:
+    // the block keeps its bits in ascending order (but for the lanes), so the phase tables of later
+    // sweeps keep finding their eight-bit windows filled
+    std::vector<int> rw;
+    for (int k = 0; k < sp->rb; ++k) rw.push_back(sp->regpos_store[k]);
+    for (int k = 0; k < sp->nwave; ++k) rw.push_back(sp->wavepos_store[k]);
+    std::sort(rw.begin(), rw.end());
+    for (int p : rw) put(p);
+    for (int k = 0; k < sp->rb; ++k) sp->reg_dest[k] = sp->dest_pos[sp->regpos_store[k]];
+    for (int k = 0; k < sp->nwave; ++k) sp->wave_dest[k] = sp->dest_pos[sp->wavepos_store[k]];
+    if (lookahead_) for (int p : ahead) put(p);
+    for (int p = 0; p < nloc_; ++p) put(p);
+    for (int p = nloc_; p < 64; ++p) sp->dest_pos[p] = (uint8_t)p;
   }
 
   static void cmul_acc(double *re, double *im, double fr, double fi) {
@@ -1166,12 +1302,12 @@ inline bool plan_has_far_tile(const PlanResult &pr) {
 }
 
 inline PlanResult plan_best(const std::vector<GateRec> &queue, int nloc, uint64_t shard, int bw, int max_rb,
-                            bool split_lanes) {
-  if (getenv("QH_WAVE_BITS")) return Planner(nloc, shard, bw, max_rb, split_lanes).plan(queue);
+                            bool split_lanes, bool allow_relayout = false) {
+  if (getenv("QH_WAVE_BITS")) return Planner(nloc, shard, bw, max_rb, split_lanes, -1, allow_relayout).plan(queue);
   PlanResult best;
   bool have = false, best_far = false;
   for (int wb : {1, 2, 0}) {
-    PlanResult pr = Planner(nloc, shard, bw, max_rb, split_lanes, wb).plan(queue);
+    PlanResult pr = Planner(nloc, shard, bw, max_rb, split_lanes, wb, allow_relayout).plan(queue);
     const bool far = plan_has_far_tile(pr);
     if (!have || (best_far && !far) || (best_far == far && pr.sweeps.size() < best.sweeps.size())) {
       best = std::move(pr);
@@ -1184,9 +1320,9 @@ inline PlanResult plan_best(const std::vector<GateRec> &queue, int nloc, uint64_
 }
 
 inline std::string plan_to_json(const std::vector<GateRec> &queue, int nloc, uint64_t shard, int bw = 128,
-                                int max_rb = kMaxRegBits, bool split_lanes = true) {
+                                int max_rb = kMaxRegBits, bool split_lanes = true, bool allow_relayout = false) {
   if (nloc < kLaneBits + 2) return "{\"sweeps\":[],\"note\":\"state too small for sweeps\"}";
-  PlanResult pr = plan_best(queue, nloc, shard, bw, max_rb, split_lanes);
+  PlanResult pr = plan_best(queue, nloc, shard, bw, max_rb, split_lanes, allow_relayout);
   std::string s = "{\"noop_gates\":" + std::to_string(pr.noop_gates) + ",\"sweeps\":[";
   char buf[384];
   for (size_t i = 0; i < pr.sweeps.size(); ++i) {
@@ -1206,6 +1342,7 @@ inline std::string plan_to_json(const std::vector<GateRec> &queue, int nloc, uin
     rp += "],\"wavepos\":[";
     for (int k = 0; k < sp.nwave; ++k) rp += (k ? "," : "") + std::to_string(sp.wavepos[k]);
     rp += "]";
+    rp += sp.relayout ? ",\"relayout\":1" : ",\"relayout\":0";
     snprintf(buf, sizeof buf,
              "%s{\"gates\":%llu,\"dense_ops\":%d,\"butterfly_ops\":%d,\"dpp_ops\":%d,\"lswap_ops\":%d,\"diag_ops\":%d,\"groups\":%zu,\"oterms\":%zu,\"table_entries\":%zu,"
              "\"regpos\":%s,\"fixed_ones\":%llu,\"ntiles\":%llu,\"alg_bytes\":%llu,\"swept_bytes\":%llu}",

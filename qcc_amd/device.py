@@ -279,8 +279,9 @@ class DeviceState:
 
   def amplitude(self, logical_index):
     """One amplitude by LOGICAL (local) index -- 16-byte D2H."""
-    p = self.logical_to_phys(logical_index) & ((1 << self.nbits) - 1)
-    return self.download(p, 1)[0]
+    out = (ctypes.c_double * 2)()
+    native.check(self.lib.qh_amplitude(self.h, int(logical_index), out))
+    return self.dtype(complex(out[0], out[1]))
 
   # -- engine measurement ---------------------------------------------------------
   def stats(self):

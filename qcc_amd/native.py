@@ -65,6 +65,7 @@ SIGNATURES = {
     'qh_phys_to_logical': (_i32, [_vp, _u64, ctypes.POINTER(_u64)]),
     'qh_logical_to_phys': (_i32, [_vp, _u64, ctypes.POINTER(_u64)]),
     'qh_norm2': (_i32, [_vp, _dp]),
+    'qh_amplitude': (_i32, [_vp, _u64, _dp]),
     'qh_argmax': (_i32, [_vp, ctypes.POINTER(_u64), _dp]),
     'qh_prob_bit': (_i32, [_vp, _i32, _dp]),
     'qh_prob_bit_value': (_i32, [_vp, _i32, _i32, _dp]),
@@ -78,6 +79,7 @@ SIGNATURES = {
     'qh_plan_export': (_i32, [_vp, _vp, _u64, ctypes.POINTER(_u64)]),
     'qh_host_apply1': (_i32, [_vp, _dp, _i32, _i32, _i32]),
     'qh_host_applyc': (_i32, [_vp, _dp, _i32, _i32, _i32, _i32]),
+    'qh_host_release': (_i32, []),
 }
 
 

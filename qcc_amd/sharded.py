@@ -485,7 +485,9 @@ class ShardedState:
     phys = self.logical_to_phys(int(logical_index))
     if (phys >> self.nloc) != self.rank:
       return None
-    return self.eng.amplitude(phys & ((1 << self.nloc) - 1))
+    local = phys & ((1 << self.nloc) - 1)
+    knows_shard = getattr(self.eng, 'nbits_global', self.nloc) > self.nloc   # (ShardedDevice sets it)
+    return self.eng.amplitude(((self.rank << self.nloc) | local) if knows_shard else local)
 
   def gather_logical(self):
     """Whole state in LOGICAL order on every rank (tests / small n only)."""

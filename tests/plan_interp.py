@@ -35,10 +35,11 @@ def export_plan(handle):
   native.check(lib.qh_plan_export(handle, None, 0, ctypes.byref(need)))
   buf = np.zeros(need.value // 8, dtype=np.uint64)
   native.check(lib.qh_plan_export(handle, buf.ctypes.data, need.value, None))
-  assert buf[0] == 0x51485031
+  assert buf[0] == 0x51485032
   nsweeps, noop = int(buf[1]), int(buf[2])
   raw = buf.view(np.uint8)
-  pos = 24
+  final_pos = [int(x) for x in raw[24:88]]
+  pos = 88
   sweeps = []
   for _ in range(nsweeps):
     hdr = raw[pos:pos + 208].view('<i8')
@@ -46,7 +47,12 @@ def export_plan(handle):
     sp = {'rb': int(hdr[0]), 'regpos': [int(x) for x in hdr[1:6]], 'regpos_store': [int(x) for x in hdr[6:11]],
           'lanehi': [int(x) for x in hdr[11:14]], 'nwave': int(hdr[14]), 'wavepos': [int(x) for x in hdr[15:17]],
           'fixed_ones': int(hdr[17]) & (2 ** 64 - 1), 'ntiles': int(hdr[18]), 'n_ltab': int(hdr[23]),
-          'lane_low': int(hdr[24])}
+          'lane_low': int(hdr[24]), 'relayout': int(hdr[25]), 'final_pos': final_pos}
+    sp['dest_pos'] = [int(x) for x in raw[pos:pos + 64]]
+    pos += 64
+    st = raw[pos:pos + 40].view('<i8')
+    pos += 40
+    sp['lanehi_store'], sp['wavepos_store'] = [int(x) for x in st[:3]], [int(x) for x in st[3:5]]
     for name, dt, count in (('ops', OP_DT, int(hdr[19])), ('groups', GROUP_DT, int(hdr[20])),
                             ('oterms', OTERM_DT, int(hdr[21])), ('tables', np.dtype('<f8'), int(hdr[22]))):
       nbytes = count * dt.itemsize
@@ -61,8 +67,21 @@ def _bit(idx, b):
   return ((idx >> np.uint64(b)) & np.uint64(1)).astype(bool)
 
 
+def permute_bits(psi, nloc, dest_pos):
+  """out[j] = psi[i] where bit p of i becomes bit dest_pos[p] of j (a relayout store)."""
+  idx = np.arange(1 << nloc, dtype=np.uint64)
+  j = np.zeros_like(idx)
+  for p in range(nloc):
+    j |= ((idx >> np.uint64(p)) & np.uint64(1)) << np.uint64(dest_pos[p])
+  out = np.empty_like(psi)
+  out[j] = psi
+  return out
+
+
 def run_plan(psi, sweeps, nloc, shard=0):
-  """Apply the exported sweeps to the LOCAL shard `psi` (2^nloc amplitudes, physical order) in place."""
+  """Apply the exported sweeps to the LOCAL shard `psi` (2^nloc amplitudes, physical order) in place.
+  Relayout sweeps move index bits: the result is returned in the ORIGINAL bit order (the inverse of
+  the plan's final_pos is applied at the end), as a caller that converts through the bit map sees it."""
   n = 1 << nloc
   idx = np.arange(n, dtype=np.uint64)
   gidx = idx | (np.uint64(shard) << np.uint64(nloc))          # global index (shard bits on top)
@@ -152,8 +171,27 @@ def run_plan(psi, sweeps, nloc, shard=0):
       a, b = psi[i0].astype(np.complex128), psi[i1].astype(np.complex128)
       psi[i0] = (m[0, 0] * a + m[0, 1] * b).astype(psi.dtype)
       psi[i1] = (m[1, 0] * a + m[1, 1] * b).astype(psi.dtype)
-    # the tile is stored with `regpos_store`; lane exchanges must have been undone
-    assert lanepos == list(range(low)) + list(sp['lanehi'][:6 - low]), 'lane layout not restored before the store'
     assert regpos == list(sp['regpos_store'][:rb]), 'store layout disagrees with the exported one'
+    if sp['relayout']:
+      # the tile goes to the second buffer contiguously: lane bits on 0..5, register bit k on 6+k,
+      # wave bit j on 6+rb+j, everything else above in order -- whatever the bits are now
+      assert fixed == 0
+      assert lanepos[low:] == list(sp['lanehi_store'][:6 - low]) and wavepos == list(sp['wavepos_store'][:sp['nwave']])
+      for k, b in enumerate(lanepos):
+        assert sp['dest_pos'][b] == k, 'the lanes of the tile are not stored on positions 0..5'
+      assert sorted(sp['dest_pos'][b] for b in regpos + wavepos) == list(range(6, 6 + len(regpos + wavepos))), \
+          'the tile is not stored contiguously'
+      assert sorted(sp['dest_pos'][:nloc]) == list(range(nloc)), 'dest_pos is not a permutation'
+      # (the other index bits may go anywhere above the tile; the kernel moves them in at most 8 runs)
+      psi[:] = permute_bits(psi, nloc, sp['dest_pos'])
+      continue
+    # in place: the tile is stored with `regpos_store`; lane exchanges must have been undone
+    assert lanepos == list(range(low)) + list(sp['lanehi'][:6 - low]), 'lane layout not restored before the store'
     assert sorted(regpos + wavepos) == sorted(list(sp['regpos'][:rb]) + list(sp['wavepos'][:sp['nwave']]))
+  if sweeps and any(sp['relayout'] for sp in sweeps):
+    fp = sweeps[0]['final_pos']
+    inv = [0] * nloc
+    for p_ in range(nloc):
+      inv[fp[p_]] = p_
+    psi[:] = permute_bits(psi, nloc, inv)
   return psi

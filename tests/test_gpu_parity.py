@@ -185,6 +185,45 @@ def test_host_dropin_entry_points(oracle):
     assert np.max(np.abs(psi - want)) <= tol
 
 
+def test_host_dropin_scratch_lifetime(oracle):
+  """qh_host_* keep per-thread device scratch for the two most recent register shapes; alternating
+  register sizes, a third shape, qh_host_release() and a second thread all give the oracle's result."""
+  import threading
+  lib = native.load()
+  dp = ctypes.POINTER(ctypes.c_double)
+  rng = np.random.default_rng(2)
+  g = _rand_unitary(rng)
+  g8 = gates.as8(g)
+
+  def one(n, bw=128):
+    psi = _rand_state(rng, n, np.complex128 if bw == 128 else np.complex64)
+    want = psi.copy()
+    native.check(lib.qh_host_apply1(psi.ctypes.data, g8.ctypes.data_as(dp), n, n - 1, bw))
+    oracle.apply1(want, g, n, n - 1)
+    native.check(lib.qh_host_applyc(psi.ctypes.data, g8.ctypes.data_as(dp), n, 0, n - 2, bw))
+    oracle.applyc(want, g, n, 0, n - 2)
+    assert np.max(np.abs(psi - want)) <= (TOL if bw == 128 else 2e-6)
+  for n in (10, 12, 10, 12, 14, 10, 12):
+    one(n)
+  one(10, 64)
+  assert lib.qh_host_release() == 0
+  assert lib.qh_host_release() == 0          # idempotent
+  one(12)
+  errs = []
+
+  def worker():
+    try:
+      one(11)
+      lib.qh_host_release()
+    except Exception as e:  # pylint: disable=broad-except
+      errs.append(e)
+  t = threading.Thread(target=worker)
+  t.start()
+  t.join()
+  assert not errs
+  lib.qh_host_release()
+
+
 def test_readers(oracle):
   n = 14
   rng = np.random.default_rng(4)

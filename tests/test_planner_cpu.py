@@ -42,15 +42,19 @@ def test_qft30_is_three_sweeps_and_accounts_every_gate():
   # sweep 1: contiguous lanes, five register bits, one wave bit (a workgroup = 2 tiles = one super-tile)
   assert sw[0]['regpos'] == [6, 7, 8, 9, 10] and sw[0]['lanehi'] == [3, 4, 5] and sw[0]['wavepos'] == [11]
   assert sw[0]['dense_ops'] == 12
-  # sweeps 2, 3: split-lane tiles: the lowest new bit in the wave id, then lanes, the highest in registers
+  # sweeps 2, 3: split-lane tiles (the lowest new bit in the wave id, then lanes, the highest in registers)
+  # gathered into the second buffer; sweep 2 leaves its own bits on 3..11 and -- looking ahead -- sweep 3's
+  # targets right above them
   assert sw[1]['wavepos'] == [12] and sw[1]['lanehi'] == [13, 14, 15] and sw[1]['regpos'] == [16, 17, 18, 19, 20]
-  assert sw[2]['wavepos'] == [21] and sw[2]['lanehi'] == [25, 26, 27] and sw[2]['regpos'] == [22, 23, 24, 28, 29]
+  assert sw[2]['wavepos'] == [12] and sw[2]['lanehi'] == [13, 14, 15] and sw[2]['regpos'] == [16, 17, 18, 19, 20]
   assert all(s['swept_bytes'] == 2 * S for s in sw)            # one read + one write each
   # all H but one per sweep run as add-only butterflies; the remaining one carries the scalars
   assert [s['butterfly_ops'] for s in sw] == [s['dense_ops'] - 1 for s in sw]
-  # sweep 1 stores the exchanged layout (one exchange); sweeps 2, 3 (split lanes) swap the wave bit
-  # into a register, move the displaced bit once more, and swap back
-  assert [s['lswap_ops'] for s in sw] == [1, 4, 4]
+  # sweep 1 (contiguous tile) runs in place and stores the exchanged layout (one exchange); sweeps 2, 3
+  # (split lanes) gather their tile and store it contiguously into the second buffer: the wave bit is
+  # swapped into a register and the displaced bit once more, and nothing is swapped back
+  assert [s['relayout'] for s in sw] == [0, 1, 1]
+  assert [s['lswap_ops'] for s in sw] == [1, 2, 2]
   # minimal-touch bytes of BASELINE.md: 30 H x 2S + 435 CU1 x S/2 = 277.5 S
   assert sum(s['alg_bytes'] for s in sw) == int(277.5 * S)
   # lazy diagonal placement + tables: (almost) no per-gate loop terms left

@@ -151,12 +151,18 @@ def gen(rb, wide=True):
     # OP_WSWAP moved between the wave id and the registers (they are not swapped back)
     blo, bhi, table = ('s24', 's25', 0x140) if store else ('%0', '%1', 0x40)
     if store:
+      # in place: the load address corrected by the index bits OP_WSWAP moved (mask = ~0);
+      # relayout sweep: the tile's own contiguous block of the second buffer (mask = 0, the
+      # kernel passes that block's address and lane offsets as the store operands)
+      a('s_load_dwordx2 s[74:75], %2, 0x28')      # SweepParams::store_delta_mask
       a('s_mov_b64 s[72:73], %3')
       a('s_sub_u32 s24, s72, s26')                # tile index now - tile index at load time
       a('s_subb_u32 s25, s73, s27')
+      a('s_waitcnt lgkmcnt(0)')
+      a('s_and_b64 s[24:25], s[24:25], s[74:75]')
       a(f's_lshl_b64 s[24:25], s[24:25], {2 + W()}')
-      a('s_add_u32 s24, s24, %0')
-      a('s_addc_u32 s25, s25, %1')
+      a('s_add_u32 s24, s24, %[sblo]')
+      a('s_addc_u32 s25, s25, %[sbhi]')
     for j in range(nr // batch):
       a(f's_load_dwordx{2 * batch} s[52:{52 + 2 * batch - 1}], %2, {table + 8 * batch * j}')
       a('s_waitcnt lgkmcnt(0)')
@@ -167,7 +173,7 @@ def gen(rb, wide=True):
         dw = 'dwordx4' if DT.wide else 'dwordx2'
         regs = f'v[{T(k)}:{T(k) + 2 * W() - 1}]'
         if store:
-          a(f'global_store_{dw} %4, {regs}, s[98:99]' + NT)
+          a(f'global_store_{dw} %[svoff], {regs}, s[98:99]' + NT)
         else:
           a(f'global_load_{dw} {regs}, %4, s[98:99]' + NT)
 
@@ -1045,7 +1051,8 @@ def gen(rb, wide=True):
           f'asm volatile(\n{body}\n'
           '    : [tidx] "+s"(tile_idx), [itlo] "+v"(it_lo), [ithi] "+v"(it_hi)\n'
           '    : [blo] "s"(base_lo), [bhi] "s"(base_hi), [prm] "s"(prm), [voff] "v"(voff), [lane] "v"(lane_u),\n'
-          '      [wave] "s"(wave_s), [lds] "s"(lds_base), [ltab] "s"(lds_ltab)\n'
+          '      [wave] "s"(wave_s), [lds] "s"(lds_base), [ltab] "s"(lds_ltab),\n'
+          '      [sblo] "s"(sbase_lo), [sbhi] "s"(sbase_hi), [svoff] "v"(svoff)\n'
           f'    : {cl});\n')
 
 
