@@ -122,8 +122,27 @@ def cpu_baseline(args, ops, g8):
   rate = len(pick) / dt
   # scale to the benchmark's state size: cost per gate is linear in 2^n
   scale = 2.0 ** (n - args.qubits_shard)
+  # all host cores, for context: our OpenMP restatement of the same loops
+  # (the reference has no threaded path), same sampled gates
+  all_cores = None
+  try:
+    omp = oracle_lib.load(omp=True)
+    omp.run_stream_mt(psi, n, o[pick[:1]], g[pick[:1]])          # thread pool + page placement warm-up
+    t1 = time.perf_counter()
+    omp.run_stream_mt(psi, n, o[pick], g[pick])
+    dt_mt = time.perf_counter() - t1
+    all_cores = {'value': len(pick) / dt_mt * scale, 'unit': 'gate-applies/s', 'cores': os.cpu_count(), 'kind': 'port',
+                 'sample': f'the same {len(pick)} gates, oracle/xgates_oracle.c oracle_run_stream_c128_mt, OpenMP, {dt_mt:.2f} s'}
+  except Exception as e:  # pylint: disable=broad-except
+    all_cores = {'error': str(e)}
+  import hashlib
+  bin_path = (os.path.join(ROOT, 'oracle', '_ref', 'libxgates.so') if kind == 'reference'
+              else os.path.join(ROOT, 'oracle', '_build', 'liboracle_fast.so'))
+  with open(bin_path, 'rb') as f:
+    bin_hash = hashlib.sha256(f.read()).hexdigest()[:16]
   return {
       'value': rate * scale, 'unit': 'gate-applies/s', 'cores': 1, 'kind': kind,
+      'binary': os.path.relpath(bin_path, ROOT), 'binary_sha16': bin_hash, 'all_cores': all_cores,
       'sample': (f'{len(pick)} gates (indices {pick.tolist()}) of the {len(o)}-gate {n}-qubit QFT stream, '
                  f'complex128, single thread, {dt:.1f} s'
                  + ('' if n == args.qubits_shard else f'; scaled x{scale:g} to 2^{args.qubits_shard} amplitudes')
@@ -228,6 +247,15 @@ def main():
   # parity guard inside the bench: closed form on sampled amplitudes after the
   # first full QFT is checked in tests; here we check the norm (cheap, device-side)
   norm2 = eng.norm2_global() if dist is not None else eng.norm2()
+  cached = None
+  if world == 1 and dist is None and fusion != native.QH_FUSE_OFF and os.environ.get('QH_PLAN_CACHE') == '0':
+    # the same steps with the engine's plan cache on (loops over one circuit skip the planner): reported
+    # beside the headline, which plans every step from scratch
+    os.environ['QH_PLAN_CACHE'] = '1'
+    w2, e2, s2 = timed_steps(eng, ops, g8, args.steps, 8, None)
+    os.environ['QH_PLAN_CACHE'] = '0'
+    cached = {'ms_per_step': w2 / args.steps * 1e3, 'event_ms_per_step': e2 / args.steps,
+              'note': 'QH_PLAN_CACHE=1, 8 extra warm-up steps (the layouts of a relayout cycle each get their plan cached)'}
 
   out = None
   if rank == 0:
@@ -277,6 +305,8 @@ def main():
         'event_ms_per_step': ev_ms / steps, 'norm2': norm2,
         'roofline': roofline,
     }
+    if cached:
+      out['cached_plan'] = cached
     if dist is not None:
       out['exchanges_per_step'] = stats.get('exchanges', 0) / steps
       out['xgmi_bytes_per_rank_per_step'] = stats.get('exchanged_bytes', 0) / steps

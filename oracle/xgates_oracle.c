@@ -121,3 +121,35 @@ int oracle_run_stream_c128(double *psi, int nbits, int64_t ngates,
   }
   return ORACLE_OK;
 }
+
+/* All-core variant of the same stream driver, for the "all cores, for context" figure of the CPU
+ * baseline: the pair loop of xgates.cc:33-40 / :56-65 flattened over the
+ * pair index j (pair j = index with a zero inserted at bit p) so that OpenMP can split it whatever
+ * the target bit is; same arithmetic per pair, in-range controls only.  Compiled with -fopenmp into
+ * _build/liboracle_omp.so; checked against the serial functions in tests/test_oracle_golden.py. */
+int oracle_run_stream_c128_mt(double *psi, int nbits, int64_t ngates,
+                              const int32_t *ops, const double *gates) {
+  if (nbits < 1 || nbits > 62) return ORACLE_BAD_QUBIT;
+  const int64_t npairs = (int64_t)1 << (nbits - 1);
+  for (int64_t k = 0; k < ngates; ++k) {
+    const int ctl = ops[2 * k], tgt = ops[2 * k + 1];
+    const int p = nbits - tgt - 1;
+    const int c = (ctl == ORACLE_NO_CTL) ? -1 : nbits - ctl - 1;
+    if (p < 0 || p >= nbits || (ctl != ORACLE_NO_CTL && (c < 0 || c >= nbits || c == p))) return ORACLE_BAD_QUBIT;
+    const double *g = gates + 8 * k;
+    const double g0r = g[0], g0i = g[1], g1r = g[2], g1i = g[3], g2r = g[4], g2i = g[5], g3r = g[6], g3i = g[7];
+    const uint64_t q2 = (uint64_t)1 << p, low = q2 - 1;
+#pragma omp parallel for schedule(static)
+    for (int64_t j = 0; j < npairs; ++j) {
+      const uint64_t i = (((uint64_t)j & ~low) << 1) | ((uint64_t)j & low);
+      if (c >= 0 && !((i >> c) & 1u)) continue;
+      double *a = psi + 2 * i, *b = psi + 2 * (i + q2);
+      const double ar = a[0], ai = a[1], br = b[0], bi = b[1];
+      a[0] = (g0r * ar - g0i * ai) + (g1r * br - g1i * bi);
+      a[1] = (g0r * ai + g0i * ar) + (g1r * bi + g1i * br);
+      b[0] = (g2r * ar - g2i * ai) + (g3r * br - g3i * bi);
+      b[1] = (g2r * ai + g2i * ar) + (g3r * bi + g3i * br);
+    }
+  }
+  return ORACLE_OK;
+}

@@ -25,6 +25,8 @@ class Oracle:
     lib.oracle_run_stream_c128.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
                                            ctypes.c_void_p, ctypes.c_void_p]
     lib.oracle_run_stream_c128.restype = ctypes.c_int
+    lib.oracle_run_stream_c128_mt.argtypes = lib.oracle_run_stream_c128.argtypes
+    lib.oracle_run_stream_c128_mt.restype = ctypes.c_int
 
   @staticmethod
   def _sfx(psi):
@@ -56,8 +58,18 @@ class Oracle:
       raise ValueError(f'oracle_run_stream rc={rc}')
 
 
-def load(fast=False):
-  name = 'liboracle_fast.so' if fast else 'liboracle.so'
+  def run_stream_mt(self, psi, nbits, ops, gates):
+    """All-core variant (OpenMP when the library was built with it): in-range controls only."""
+    assert psi.dtype == np.complex128 and psi.flags.c_contiguous
+    ops = np.ascontiguousarray(ops, dtype=np.int32)
+    gates = np.ascontiguousarray(gates, dtype=np.float64)
+    rc = self.lib.oracle_run_stream_c128_mt(psi.ctypes.data, nbits, len(ops), ops.ctypes.data, gates.ctypes.data)
+    if rc:
+      raise ValueError(f'oracle_run_stream_mt rc={rc}')
+
+
+def load(fast=False, omp=False):
+  name = 'liboracle_omp.so' if omp else ('liboracle_fast.so' if fast else 'liboracle.so')
   path = os.path.join(ROOT, 'oracle', '_build', name)
   if not os.path.exists(path):
     subprocess.check_call(['make', '-C', os.path.join(ROOT, 'oracle'), '_build/' + name])

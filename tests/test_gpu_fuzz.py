@@ -10,7 +10,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize('env', [{}, {'QH_WAVE_BITS': '2', 'QH_LANE_VALU': '2'}, {'QH_WAVE_BITS': '0', 'QH_SWEEP_RB': '4', 'QH_PROPAGATE_X': '0'}])
+@pytest.mark.parametrize('env', [{}, {'QH_WAVE_BITS': '2', 'QH_LANE_VALU': '2'}, {'QH_WAVE_BITS': '0', 'QH_SWEEP_RB': '4', 'QH_PROPAGATE_X': '0'},
+                                 {'QH_RELAYOUT': '0'}, {'QH_RELAYOUT_AHEAD': '0', 'QH_WAVE_BITS': '1'}])
 def test_fuzz_fused_vs_oracle(env):
   e = dict(os.environ)
   e.update(env)

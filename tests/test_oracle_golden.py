@@ -143,6 +143,27 @@ def test_reference_libq_gate_set_equals_dense_semantics(oracle, golden_dir):
   assert seen >= {'x', 'y', 'z', 'h', 't', 'u1', 'cu1', 'cx', 'cz', 'ccx', 'walsh'}
 
 
+def test_all_core_variant_equals_serial(golden_dir):
+  """oracle_run_stream_c128_mt (the all-core CPU-baseline leg of bench.py) against the serial
+  restatement on recorded reference traces and a random stream; serial and OpenMP builds."""
+  from qcc_amd import workloads
+  for omp in (False, True):
+    o = oracle_lib.load(omp=omp)
+    for f in ('g5_supremacy_n12_s0.npz', 'g5_grover6.npz', 'g5_qft_iqft_n10.npz'):
+      g = _load(golden_dir, f)
+      psi = g['init'].astype(np.complex128).copy()
+      o.run_stream_mt(psi, int(g['nbits']), g['ops'], g['gates'])
+      assert np.max(np.abs(psi - g['final'])) <= 5e-14, (f, omp)
+    n = 17
+    ops, g8 = workloads.qft_stream(range(n)).arrays()
+    a = np.zeros(1 << n, dtype=np.complex128)
+    a[12345] = 1
+    b = a.copy()
+    o.run_stream(a, n, ops, g8)
+    o.run_stream_mt(b, n, ops, g8)
+    assert np.max(np.abs(a - b)) < 1e-15
+
+
 def test_negative_controls_are_covered(golden_dir):
   g = _load(golden_dir, 'g5_negctl.npz')
   ctl = g['ops'][:, 0]
