@@ -42,6 +42,7 @@ def parse():
   ap.add_argument('--no-ladder-base', action='store_true', help='N=1: skip the extra 33-qubit measurement')
   ap.add_argument('--fusion', type=int, default=-1, help='0 per-gate kernels, 1 fused sweeps (default)')
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--no-cached-plan', action='store_true', help='skip the extra steps timed with the plan cache on')
   ap.add_argument('--sharded', action='store_true', help='use the multi-GPU layer even with one rank (smoke)')
   ap.add_argument('--cpu-qubits', type=int, default=30)
   ap.add_argument('--cpu-gates', type=int, default=14, help='gates of the stream timed on the CPU')
@@ -248,7 +249,8 @@ def main():
   # first full QFT is checked in tests; here we check the norm (cheap, device-side)
   norm2 = eng.norm2_global() if dist is not None else eng.norm2()
   cached = None
-  if world == 1 and dist is None and fusion != native.QH_FUSE_OFF and os.environ.get('QH_PLAN_CACHE') == '0':
+  if (world == 1 and dist is None and fusion != native.QH_FUSE_OFF and os.environ.get('QH_PLAN_CACHE') == '0'
+      and not args.no_cached_plan):
     # the same steps with the engine's plan cache on (loops over one circuit skip the planner): reported
     # beside the headline, which plans every step from scratch
     os.environ['QH_PLAN_CACHE'] = '1'

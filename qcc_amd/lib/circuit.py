@@ -67,6 +67,35 @@ def _sqrt2x2(u):
     return (u + s * np.eye(2)) / t
 
 
+class _LazyPsi:
+    """What measure_bit() hands back as the state (circuit.py:287-297 returns (prob, psi)): nothing is
+    copied from the device until the caller actually looks at it -- most callers only want the
+    probability.  Like the reference's in-place State it shows the circuit's state at the time it is
+    READ (src/lib/xgates.cc:37-38 mutates the one buffer every holder of `psi` sees)."""
+
+    def __init__(self, owner):
+        self._owner = owner
+
+    def _get(self):
+        return self._owner.psi
+
+    def __array__(self, dtype=None, copy=None):
+        a = np.asarray(self._get())
+        return a.astype(dtype) if dtype is not None else a
+
+    def __getattr__(self, name):
+        return getattr(self._get(), name)
+
+    def __getitem__(self, key):
+        return self._get()[key]
+
+    def __len__(self):
+        return len(self._get())
+
+    def __iter__(self):
+        return iter(self._get())
+
+
 class qc:
     """State + gate application + (optional) IR recording."""
 
@@ -382,8 +411,7 @@ class qc:
             dev.scale(1.0 / math.sqrt(prob))
             self._host_ok = False
             self._is_product = False
-        snapshot = self.psi if self._nbits <= 26 else None
-        return prob, snapshot
+        return prob, _LazyPsi(self)
 
     def pauli_expectation(self, idx):
         p0, _ = self.measure_bit(idx, 0, False)

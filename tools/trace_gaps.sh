@@ -2,7 +2,7 @@
 # timeline of the fused bench (GPU box): every kernel with start offset, duration and the gap before it
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
-rm -rf /tmp/tg && timeout 300 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/tg -o t -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-ladder-base "$@" > /tmp/tg.log 2>&1
+rm -rf /tmp/tg && timeout 300 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/tg -o t -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-ladder-base --no-cached-plan "$@" > /tmp/tg.log 2>&1
 python3 - <<'PY'
 import csv, glob
 rows = []

@@ -2,7 +2,7 @@
 # per-launch durations of the fused bench (run on the GPU box)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
-rm -rf /tmp/tr && timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr -o t -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-ladder-base "$@" > /tmp/tr.log 2>&1
+rm -rf /tmp/tr && timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr -o t -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-ladder-base --no-cached-plan "$@" > /tmp/tr.log 2>&1
 python - <<'PY'
 import csv, glob
 f = glob.glob('/tmp/tr/**/t_kernel_trace.csv', recursive=True)[0]
