@@ -98,6 +98,9 @@ class ShardedState:
     self.cdtype = np.complex128 if self.bit_width == 128 else np.complex64
     factory = engine_factory or (lambda nloc: _hip_engine_factory(nloc, local_rank, fusion, self.bit_width))
     self.eng, self.buf = factory(self.nloc)
+    self._hip = hasattr(self.eng, 'lib')          # the real engine: knows its shard, builds states on the device
+    if self._hip:
+      self.eng.set_shard(self.nbits, self.rank)
     # logical bit b (0 = least significant; qubit q is bit nbits-1-q) -> physical bit
     self.perm = list(range(self.nbits))
     self.chunk = min(int(chunk_amps), 1 << (self.nloc - 1))
@@ -175,6 +178,9 @@ class ShardedState:
   def init_basis(self, index):
     """|index> (logical); only the owning rank gets the 1."""
     phys = self.logical_to_phys(int(index))
+    if self._hip:
+      self.eng.init_basis(phys)             # (the engine's own bit map is the identity: physical == its logical)
+      return
     self.eng.sync()
     self.buf.zero_()
     if self.buf.is_cuda:
@@ -463,6 +469,8 @@ class ShardedState:
     return 'cpu' if self.dist.get_backend() == 'gloo' else self.buf.device
 
   def norm2_global(self):
+    if self.exchange_path == 'rccl':          # 8 bytes over the engine's own communicator
+      return float(self.eng.allreduce_sum([self.eng.norm2()])[0])
     t = self.torch.tensor([self.eng.norm2()], dtype=self.torch.float64, device=self._red_device())
     self.dist.all_reduce(t)
     return float(t.item())
@@ -561,9 +569,7 @@ class ShardedDevice:
     self.nbits, self.bit_width = int(nbits), int(bit_width)
     self.dtype = self.st.cdtype
     st = self.st
-    self._hip = hasattr(st.eng, 'lib')        # the real engine (device readers, init_product on the shard)
-    if self._hip:
-      st.eng.set_shard(st.nbits, st.rank)     # global bit positions for the engine's readers / product init
+    self._hip = st._hip                       # the real engine (device readers, init_product on the shard)
 
   # -- helpers ---------------------------------------------------------------------
   def _local_view(self):
