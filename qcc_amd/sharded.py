@@ -78,6 +78,9 @@ class ShardedState:
       # QCC_DIST_BACKEND=gloo: several ranks on ONE GPU (tests of this layer); RCCL refuses that
       backend = backend or os.environ.get('QCC_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
       os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+      if 'RANK' not in os.environ and 'WORLD_SIZE' not in os.environ:   # not under torchrun: a world of one
+        os.environ.update(RANK='0', WORLD_SIZE='1')
+        os.environ.setdefault('MASTER_PORT', '29533')
       kw = {}
       if backend == 'nccl' and local_rank is not None:
         torch.cuda.set_device(local_rank)
