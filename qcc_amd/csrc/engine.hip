@@ -1070,6 +1070,11 @@ int comm_common_init(qh_state_s *h, int nranks, int rank) {
     return fail(QH_ERR_ARG, "nranks %d must be a power of two, rank %d inside it", nranks, rank);
   if (h->bw != 128 && h->bw != 64) return fail(QH_ERR_BAD_DTYPE, "bit width");
   HIP_TRY(hipSetDevice(h->device));
+  // exchanges address PHYSICAL index bits: from here on sweeps stay in place, so bring the state
+  // back to canonical order if earlier flushes re-laid it out
+  int rc0 = flush_impl(h);
+  if (rc0 == QH_OK) rc0 = canonicalize(h);
+  if (rc0) return rc0;
   auto *c = new qh::Comm;
   c->nranks = nranks;
   c->rank = rank;

@@ -54,12 +54,13 @@ def test_loopback_exchange_equals_x_gate(oracle, transport, n, bit, chunk, bw):
   for o, g in ((a_ops, a_g), (q_ops, q_g), (x_ops, x_g), (b_ops, b_g), (x_ops, x_g), (x_ops, x_g)):
     oracle.run_stream(want, n, o, g)
   with device.DeviceState(n, bw, fusion=native.QH_FUSE_SWEEP) as st:
-    if transport == 'rccl':
+    st.init_basis(5)
+    st.run_stream(a_ops, a_g)
+    st.flush()                         # (an owning handle may re-lay the state out here: the communicator
+    if transport == 'rccl':            #  attaches to a canonical layout again)
       st.comm_init(1, 0, device.DeviceState.comm_unique_id())
     else:
       st.comm_init_custom(1, 0, _self_round)
-    st.init_basis(5)
-    st.run_stream(a_ops, a_g)
     st.run_stream(q_ops, q_g)          # left queued: the exchange runs it, last sweep slab by slab
     st.exchange_loopback(bit, chunk)
     st.run_stream(b_ops, b_g)          # first sweep starts slab by slab as the slabs arrive
