@@ -153,3 +153,14 @@ int oracle_run_stream_c128_mt(double *psi, int nbits, int64_t ngates,
   }
   return ORACLE_OK;
 }
+
+/* First-touch initialisation by the threads that will work on the pages (NUMA placement of the
+ * all-core baseline): psi := |index>. */
+int oracle_init_basis_c128_mt(double *psi, int nbits, uint64_t index) {
+  if (nbits < 1 || nbits > 62) return ORACLE_BAD_QUBIT;
+  const int64_t n2 = (int64_t)2 << nbits;
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n2; ++i) psi[i] = 0.0;
+  psi[2 * index] = 1.0;
+  return ORACLE_OK;
+}

@@ -27,6 +27,8 @@ class Oracle:
     lib.oracle_run_stream_c128.restype = ctypes.c_int
     lib.oracle_run_stream_c128_mt.argtypes = lib.oracle_run_stream_c128.argtypes
     lib.oracle_run_stream_c128_mt.restype = ctypes.c_int
+    lib.oracle_init_basis_c128_mt.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64]
+    lib.oracle_init_basis_c128_mt.restype = ctypes.c_int
 
   @staticmethod
   def _sfx(psi):
@@ -57,6 +59,13 @@ class Oracle:
     if rc:
       raise ValueError(f'oracle_run_stream rc={rc}')
 
+
+  def init_basis_mt(self, psi, nbits, index):
+    """psi := |index>, pages first touched by the OpenMP threads that will work on them."""
+    assert psi.dtype == np.complex128 and psi.flags.c_contiguous and psi.size == 1 << nbits
+    rc = self.lib.oracle_init_basis_c128_mt(psi.ctypes.data, nbits, int(index))
+    if rc:
+      raise ValueError(f'oracle_init_basis_mt rc={rc}')
 
   def run_stream_mt(self, psi, nbits, ops, gates):
     """All-core variant (OpenMP when the library was built with it): in-range controls only."""

@@ -158,7 +158,9 @@ def test_all_core_variant_equals_serial(golden_dir):
     ops, g8 = workloads.qft_stream(range(n)).arrays()
     a = np.zeros(1 << n, dtype=np.complex128)
     a[12345] = 1
-    b = a.copy()
+    b = np.empty(1 << n, dtype=np.complex128)
+    o.init_basis_mt(b, n, 12345)
+    assert np.array_equal(a, b)
     o.run_stream(a, n, ops, g8)
     o.run_stream_mt(b, n, ops, g8)
     assert np.max(np.abs(a - b)) < 1e-15
