@@ -220,7 +220,8 @@ int qh_plan_json(qh_handle h, char *buf, uint64_t cap, uint64_t *needed);
  * the index bit at each position before it), then per sweep 26 x i64 (rb, regpos[5],
  * regpos_store[5], lanehi[3], nwave, wavepos[2], fixed_ones, ntiles, #ops, #groups, #oterms,
  * #table doubles, #lane tables, lane_low, relayout), 64 bytes dest_pos, 5 x i64 (lanehi and wavepos
- * at store time), followed by the SweepOp / DGroup / OTerm / table arrays of
+ * at store time), 24 x i64 (relayout store as the kernel gets it: reg_dest[5], wave_dest[2], number of
+ * unit-index runs, 8 masks, 8 shifts), followed by the SweepOp / DGroup / OTerm / table arrays of
  * qcc_amd/csrc/planner.h, each padded to 8 bytes.  For tools and tests that check a plan
  * without a GPU (tests/plan_interp.py executes it with NumPy).                 */
 int qh_plan_export(qh_handle h, void *buf, uint64_t cap, uint64_t *needed);

@@ -1036,6 +1036,17 @@ int qh_plan_export(qh_handle h, void *buf, uint64_t cap, uint64_t *needed) {
     {
       int64_t st[5] = {sp.lanehi_store[0], sp.lanehi_store[1], sp.lanehi_store[2], sp.wavepos_store[0], sp.wavepos_store[1]};
       put_bytes(st, sizeof st);
+      // what the kernel is handed for a relayout store: register / wave bit destinations and the runs of
+      // unit-index bits (count, then 8 x mask, 8 x shift)
+      int64_t kd[7 + 1 + 2 * qh::kMaxUnitSegs] = {0};
+      for (int i = 0; i < 5; ++i) kd[i] = sp.reg_dest[i];
+      kd[5] = sp.wave_dest[0];
+      kd[6] = sp.wave_dest[1];
+      uint64_t masks[qh::kMaxUnitSegs] = {0};
+      int shifts[qh::kMaxUnitSegs] = {0};
+      kd[7] = sp.relayout ? qh::unit_segments(sp, h->nloc, masks, shifts) : 0;
+      for (int i = 0; i < qh::kMaxUnitSegs; ++i) { kd[8 + i] = (int64_t)masks[i]; kd[8 + qh::kMaxUnitSegs + i] = shifts[i]; }
+      put_bytes(kd, sizeof kd);
     }
     put_bytes(sp.ops.data(), sp.ops.size() * sizeof(qh::SweepOp));
     put_bytes(sp.groups.data(), sp.groups.size() * sizeof(qh::DGroup));

@@ -53,6 +53,10 @@ def export_plan(handle):
     st = raw[pos:pos + 40].view('<i8')
     pos += 40
     sp['lanehi_store'], sp['wavepos_store'] = [int(x) for x in st[:3]], [int(x) for x in st[3:5]]
+    kd = raw[pos:pos + 192].view('<i8')
+    pos += 192
+    sp['reg_dest'], sp['wave_dest'] = [int(x) for x in kd[:5]], [int(x) for x in kd[5:7]]
+    sp['unit_runs'] = [(int(kd[8 + i]) & (2 ** 64 - 1), int(kd[16 + i])) for i in range(int(kd[7]))]
     for name, dt, count in (('ops', OP_DT, int(hdr[19])), ('groups', GROUP_DT, int(hdr[20])),
                             ('oterms', OTERM_DT, int(hdr[21])), ('tables', np.dtype('<f8'), int(hdr[22]))):
       nbytes = count * dt.itemsize
@@ -183,6 +187,23 @@ def run_plan(psi, sweeps, nloc, shard=0):
           'the tile is not stored contiguously'
       assert sorted(sp['dest_pos'][:nloc]) == list(range(nloc)), 'dest_pos is not a permutation'
       # (the other index bits may go anywhere above the tile; the kernel moves them in at most 8 runs)
+      # ... and what the kernel is handed says the same as dest_pos: slot / wave offsets and the runs of
+      # unit-index bits, applied to every unit number
+      assert [sp['dest_pos'][b] for b in regpos] == sp['reg_dest'][:rb]
+      assert [sp['dest_pos'][b] for b in wavepos] == sp['wave_dest'][:len(wavepos)]
+      tile_bits = set(lanepos + regpos + wavepos)
+      outside = [b for b in range(nloc) if b not in tile_bits]
+      tb = len(tile_bits)
+      assert 1 <= len(sp['unit_runs']) <= 8
+      units = np.arange(1 << len(outside), dtype=np.uint64)
+      moved = np.zeros_like(units)
+      for mask, shift in sp['unit_runs']:
+        part = units & np.uint64(mask)
+        moved |= (part << np.uint64(shift)) if shift >= 0 else (part >> np.uint64(-shift))
+      want_u = np.zeros_like(units)
+      for i, b in enumerate(outside):
+        want_u |= ((units >> np.uint64(i)) & np.uint64(1)) << np.uint64(sp['dest_pos'][b] - tb)
+      assert np.array_equal(moved, want_u), 'unit-index runs disagree with dest_pos'
       psi[:] = permute_bits(psi, nloc, sp['dest_pos'])
       continue
     # in place: the tile is stored with `regpos_store`; lane exchanges must have been undone
