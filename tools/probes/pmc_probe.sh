@@ -1,7 +1,7 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
-rm -rf /tmp/sqp && timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d /tmp/sqp -o t -- python $R/tools/sweep_probe.py 30 > /tmp/sqp.log 2>&1
+rm -rf /tmp/sqp && timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d /tmp/sqp -o t -- python $R/tools/probes/sweep_probe.py 30 > /tmp/sqp.log 2>&1
 grep case /tmp/sqp.log | cut -c1-90
 python - <<'PY'
 import csv, glob, collections

@@ -3,7 +3,7 @@
 access pattern of k_sweep from its arithmetic."""
 import json, os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from qcc_amd import device, gates, native
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 st = device.DeviceState(n, 128, fusion=native.QH_FUSE_SWEEP)

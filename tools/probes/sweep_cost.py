@@ -5,7 +5,7 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from qcc_amd import device, gates, native, workloads  # noqa: E402
 
 n = 30
@@ -50,6 +50,12 @@ qops, qg = workloads.qft_stream(range(n - 12, n)).arrays()     # QFT on the 12 l
 gl = [(int(c), int(t), qg[k].view(np.complex128)) for k, (c, t) in enumerate(qops)]
 timed('QFT on bits 0..11 (12 H + 66 CU1)', gl)
 timed('66 CU1 on bits 0..11 only', [x for x in gl if x[0] != NO])
+def sub(pred):
+  return [x for x in gl if x[0] == NO or pred(n - 1 - x[0], n - 1 - x[1])]
+timed('12 H + CU1 among lane bits 0..5 (15)', sub(lambda a, b: a < 6 and b < 6))
+timed('12 H + CU1 among bits 6..11 (15)', sub(lambda a, b: a >= 6 and b >= 6))
+timed('12 H + CU1 lane x reg (36)', sub(lambda a, b: (a < 6) != (b < 6)))
+timed('12 H + CU1 with bits 0..2 only', sub(lambda a, b: min(a, b) < 3))
 # mid geometry
 mid = [0, 1, 2] + list(range(12, 21))
 timed('12 H on bits 0,1,2,12..20 (in place)', [(NO, q(b), h) for b in mid])
