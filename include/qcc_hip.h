@@ -73,6 +73,12 @@ int qh_create(int nbits, int bit_width, int device, qh_handle *out);
  * (engine creates its own).                                                  */
 int qh_attach(int nbits, int bit_width, int device, void *device_ptr,
               void *hip_stream, qh_handle *out);
+/* The state in pinned host memory the GPU works on directly (zero copy): for SMALL registers whose
+ * owner wants the reference's contract literally -- apply1/applyc mutate the caller-visible buffer in
+ * place (xgates.cc:37-38) and every holder of that buffer sees it.  qh_host_ptr gives the host
+ * address (valid until qh_destroy; read it after qh_sync).  Every gate crosses PCIe: <= 28 qubits.   */
+int qh_create_host_mapped(int nbits, int bit_width, int device, qh_handle *out);
+int qh_host_ptr(qh_handle h, void **host_ptr);   /* NULL for states that live in HBM */
 /* Planner-only handle: no device, no memory.  Gates can be queued and the
  * plan inspected with qh_plan_json (used by CPU-side tests).                 */
 int qh_create_dry(int nbits, int bit_width, qh_handle *out);

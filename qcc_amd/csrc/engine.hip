@@ -53,6 +53,7 @@ struct qh_state_s {
   int nloc = 0, nglob = 0, bw = 128, device = 0;
   uint64_t shard = 0;
   void *d_psi = nullptr;
+  void *host_psi = nullptr;    // qh_create_host_mapped: the pinned, GPU-visible host allocation d_psi points into
   void *d_alt = nullptr;       // second buffer of the same size: target of relayout sweeps (lazily allocated)
   int relayout = -1;           // -1 undecided, 0 off (attached memory, no room, QH_RELAYOUT=0), 1 on
   bool owns_mem = false, owns_stream = false, dry = false;
@@ -504,6 +505,37 @@ int qh_create(int nbits, int bit_width, int device, qh_handle *out) {
   return QH_OK;
 }
 
+int qh_create_host_mapped(int nbits, int bit_width, int device, qh_handle *out) {
+  if (!out) return fail(QH_ERR_ARG, "null out");
+  int rc = check_args(nbits, bit_width);
+  if (rc) return rc;
+  if (nbits > 28) return fail(QH_ERR_ARG, "host-mapped states are for small registers (<= 28 qubits): every gate crosses PCIe");
+  rc = select_device(device);
+  if (rc) return rc;
+  void *host = nullptr, *dev = nullptr;
+  const size_t bytes = (size_t)(bit_width == 128 ? 16 : 8) << nbits;
+  hipError_t e = hipHostMalloc(&host, bytes, hipHostMallocMapped);
+  if (e == hipSuccess) e = hipHostGetDevicePointer(&dev, host, 0);
+  if (e != hipSuccess) {
+    if (host) (void)hipHostFree(host);
+    return fail(QH_ERR_NOMEM, "hipHostMalloc(%zu bytes, mapped): %s", bytes, hipGetErrorString(e));
+  }
+  memset(host, 0, bytes);
+  rc = qh_attach(nbits, bit_width, device, dev, nullptr, out);
+  if (rc) {
+    (void)hipHostFree(host);
+    return rc;
+  }
+  (*out)->host_psi = host;
+  return QH_OK;
+}
+
+int qh_host_ptr(qh_handle h, void **host_ptr) {
+  if (!h || !host_ptr) return fail(QH_ERR_ARG, "null");
+  *host_ptr = h->host_psi;
+  return QH_OK;
+}
+
 int qh_attach(int nbits, int bit_width, int device, void *device_ptr, void *hip_stream,
               qh_handle *out) {
   if (!out || !device_ptr) return fail(QH_ERR_ARG, "null pointer");
@@ -561,6 +593,7 @@ int qh_destroy(qh_handle h) {
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->owns_mem && h->d_psi) (void)hipFree(h->d_psi);
     if (h->d_alt) (void)hipFree(h->d_alt);
+    if (h->host_psi) (void)hipHostFree(h->host_psi);
     if (h->owns_stream && h->stream) (void)hipStreamDestroy(h->stream);
   }
   delete h;

@@ -64,13 +64,15 @@ class DeviceState:
   """Owns a qh_handle.  complex128 (bit_width=128) or complex64 (64)."""
 
   def __init__(self, nbits, bit_width=128, device=0, fusion=native.QH_FUSE_OFF, *,
-               device_ptr=None, stream=None):
+               device_ptr=None, stream=None, host_mapped=False):
     self.lib = native.load()
     self.nbits = int(nbits)
     self.bit_width = int(bit_width)
     self.dtype = np.complex128 if bit_width == 128 else np.complex64
     h = ctypes.c_void_p()
-    if device_ptr is None:
+    if host_mapped:
+      native.check(self.lib.qh_create_host_mapped(self.nbits, self.bit_width, device, ctypes.byref(h)))
+    elif device_ptr is None:
       native.check(self.lib.qh_create(self.nbits, self.bit_width, device, ctypes.byref(h)))
     else:
       native.check(self.lib.qh_attach(self.nbits, self.bit_width, device,
@@ -106,6 +108,17 @@ class DeviceState:
   def set_shard(self, nbits_global, shard_index):
     native.check(self.lib.qh_set_shard(self.h, int(nbits_global), int(shard_index)))
     self.nbits_global = int(nbits_global)
+
+  def host_array(self):
+    """NumPy view of a host-mapped state (qh_create_host_mapped): the very memory the GPU works on.
+    Call sync() before reading."""
+    p = ctypes.c_void_p()
+    native.check(self.lib.qh_host_ptr(self.h, ctypes.byref(p)))
+    if not p.value:
+      raise ValueError('this state lives in HBM (create it with host_mapped=True)')
+    real = ctypes.c_double if self.bit_width == 128 else ctypes.c_float
+    flat = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(real)), shape=(2 << self.nbits,))
+    return flat.view(self.dtype)
 
   @property
   def device_ptr(self):

@@ -79,6 +79,22 @@ def _default_device_factory(nbits, bit_width):
                               device=int(os.environ.get('LOCAL_RANK', '0')) if world > 1 else 0)
 
 
+def make_host_mapped_state(nbits, bit_width):
+    """The state in pinned host memory the GPU works on in place (circuit.qc(alias_psi=True))."""
+    if _host_mapped_factory is not None:
+        return _host_mapped_factory(nbits, bit_width)
+    from qcc_amd import device
+    return device.DeviceState(nbits, bit_width, fusion=native.QH_FUSE_SWEEP, host_mapped=True)
+
+
+_host_mapped_factory = None
+
+
+def set_host_mapped_factory(factory):
+    global _host_mapped_factory
+    _host_mapped_factory = factory
+
+
 def make_device_state(nbits, bit_width):
     return (_device_factory or _default_device_factory)(nbits, bit_width)
 

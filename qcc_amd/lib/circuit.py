@@ -19,6 +19,11 @@ Host-visible state contract:
   * registers created with ``reg``/``zeros``/``ones``/``bitstring`` on a circuit
     that is still a basis state never materialise 2^n amplitudes on the host
     (the reference does: circuit.py:121-129 -> np.kron).
+  * ``qc(..., alias_psi=True)`` (or QCC_ALIAS_PSI=1), registers up to 26 qubits: the reference's contract
+    LITERALLY -- the state lives in pinned host memory the GPU works on in place (qh_create_host_mapped),
+    ``qc.psi`` is a writable State over that very memory, every gate is complete when its call returns,
+    and ``p = qc.psi; qc.h(0)`` changes ``p`` (src/lib/xgates.cc:37-38).  Every gate crosses PCIe and is
+    waited for: for code that depends on the aliasing, not for speed.
 """
 import math
 
@@ -43,6 +48,7 @@ except Exception:  # pylint: disable=broad-except
     _flags = None
 
 _SNAPSHOT_LIMIT_BITS = 31  # above this a full host snapshot is refused (>= 32 GiB)
+_ALIAS_LIMIT_BITS = 26     # alias_psi: registers up to this size live in host-mapped memory
 
 
 def _dump_flags_set():
@@ -99,8 +105,10 @@ class _LazyPsi:
 class qc:
     """State + gate application + (optional) IR recording."""
 
-    def __init__(self, name=None, eager=True):
+    def __init__(self, name=None, eager=True, alias_psi=None):
         self.name = name
+        import os as _os
+        self._alias = bool(_os.environ.get('QCC_ALIAS_PSI') == '1' if alias_psi is None else alias_psi)
         self.ir = ir.Ir()
         self.eager = eager
         self.build_ir = not eager
@@ -143,10 +151,14 @@ class qc:
         if self._nbits == 0:
             raise ValueError('circuit has no qubits yet')
         if self._dev is not None and (self._dev.nbits != self._nbits or self._dev.bit_width != self._width()):
-            self._dev.close()
+            if not self._alias:
+                self._dev.close()     # (alias mode: State views handed out keep the mapped memory alive)
             self._dev, self._dev_ok = None, False
         if self._dev is None:
-            self._dev = backend.make_device_state(self._nbits, self._width())
+            if self._alias and self._nbits <= _ALIAS_LIMIT_BITS:
+                self._dev = backend.make_host_mapped_state(self._nbits, self._width())
+            else:
+                self._dev = backend.make_device_state(self._nbits, self._width())
         if not self._dev_ok:
             if self._is_product:
                 self._dev.init_product(self._factors)
@@ -154,12 +166,25 @@ class qc:
                 assert self._host_ok, 'no valid copy of the state'
                 self._dev.upload(np.asarray(self._host))
             self._dev_ok = True
+            if self._aliased():
+                self._host, self._host_ok = None, False   # from now on THE state is the mapped buffer
         return self._dev
+
+    def _aliased(self):
+        return self._alias and self._nbits and self._nbits <= _ALIAS_LIMIT_BITS
 
     @property
     def psi(self):
         if self._nbits == 0:
             return state.State(1.0)
+        if self._aliased():
+            dev = self._ensure_device()
+            dev.sync()
+            if self._host is None or not self._host_ok:
+                view = state.State(dev.host_array())      # zero copy: the mapped memory itself
+                view._keepalive = dev                     # pylint: disable=protected-access
+                self._host, self._host_ok = view, True
+            return self._host
         if not self._host_ok:
             if self._nbits > _SNAPSHOT_LIMIT_BITS:
                 raise MemoryError(f'qc.psi would copy 2^{self._nbits} amplitudes to the host; use qc.maxprob(), '
@@ -185,6 +210,12 @@ class qc:
         host = value if isinstance(value, state.State) else state.State(value)
         if host.dtype != tensor.tensor_type():
             host = state.State(host)
+        if (self._aliased() and self._dev is not None and self._dev_ok and host.ndim and host.nbits == self._nbits
+                and self._dev.bit_width == self._width()):
+            self._dev.sync()
+            np.copyto(self._dev.host_array(), np.asarray(host))     # same register: the mapped buffer stays THE state
+            self._is_product = False
+            return
         self._nbits = host.nbits if host.ndim else 0
         self._host, self._host_ok = host, True
         self._dev_ok = False
@@ -295,8 +326,7 @@ class qc:
             if self.eager:
                 assert idx < self._nbits, 'Invalid qubit index'
                 self._ensure_device().apply1(np.asarray(gate).reshape(4), idx)
-                self._host_ok = False
-                self._is_product = False
+                self._gate_done()
 
     def applyc(self, gate, ctl, idx, name=None, *, val=None):
         """Apply `gate` on `idx` controlled by `ctl` ([ctl] = controlled by |0>)."""
@@ -310,9 +340,15 @@ class qc:
         if self.eager:
             assert idx < self._nbits, 'Invalid qubit index'
             self._ensure_device().applyc(np.asarray(gate).reshape(4), ctl_qubit, idx)
-            self._host_ok = False
-            self._is_product = False
+            self._gate_done()
         self.x(ctl_qubit, by_0)
+
+    def _gate_done(self):
+        self._is_product = False
+        if self._aliased():
+            self._dev.sync()          # the reference's calls are synchronous: holders of qc.psi see the gate now
+        else:
+            self._host_ok = False
 
     def cx0(self, idx0, idx1):
         xgate = ops.PauliX()
@@ -409,8 +445,7 @@ class qc:
             assert prob > 1e-20, 'Measurement collapses to 0.0.'
             dev.project_bit(bit, 1 if tostate else 0)
             dev.scale(1.0 / math.sqrt(prob))
-            self._host_ok = False
-            self._is_product = False
+            self._gate_done()
         return prob, _LazyPsi(self)
 
     def pauli_expectation(self, idx):
@@ -553,5 +588,6 @@ class qc:
 
     def close(self):
         if self._dev is not None:
-            self._dev.close()
+            if not self._alias:
+                self._dev.close()
             self._dev, self._dev_ok = None, False

@@ -43,6 +43,8 @@ SIGNATURES = {
     'qh_create': (_i32, [_i32, _i32, _i32, ctypes.POINTER(_vp)]),
     'qh_attach': (_i32, [_i32, _i32, _i32, _vp, _vp, ctypes.POINTER(_vp)]),
     'qh_create_dry': (_i32, [_i32, _i32, ctypes.POINTER(_vp)]),
+    'qh_create_host_mapped': (_i32, [_i32, _i32, _i32, ctypes.POINTER(_vp)]),
+    'qh_host_ptr': (_i32, [_vp, ctypes.POINTER(_vp)]),
     'qh_destroy': (_i32, [_vp]),
     'qh_set_shard': (_i32, [_vp, _i32, _u64]),
     'qh_device_ptr': (_i32, [_vp, ctypes.POINTER(_vp)]),

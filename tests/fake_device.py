@@ -23,6 +23,10 @@ class OracleDevice:
   def close(self):
     pass
 
+  def host_array(self):
+    """stand-in for a host-mapped state (device.DeviceState.host_array): THE buffer gates work on"""
+    return self.psi
+
   def init_basis(self, index=0):
     self.psi[:] = 0
     self.psi[index] = 1

@@ -209,3 +209,38 @@ def helper_bits(bits):
   for b in bits:
     v = (v << 1) | int(b)
   return v
+
+
+def test_alias_psi_contract_on_host_mapped_memory(oracle):
+  """circuit.qc(alias_psi=True): the state lives in pinned host memory the GPU works on in place
+  (qh_create_host_mapped); `p = qc.psi; qc.h(0)` changes `p` exactly as the reference's in-place
+  xgates.cc:37-38 does.  Same checks as the CPU stand-in (tests/test_lib_host_logic.py)."""
+  from tests.test_lib_host_logic import alias_contract
+
+  def apply(psi, n, gl):
+    for c, t, g in gl:
+      if c is None:
+        oracle.apply1(psi, np.asarray(g).reshape(4), n, t)
+      else:
+        oracle.applyc(psi, np.asarray(g).reshape(4), n, c, t)
+  made = []
+
+  def make():
+    qc = circuit.qc('alias', alias_psi=True)
+    made.append(qc)
+    return qc
+  alias_contract(make, apply)
+  assert type(made[0]._dev).__module__ == 'qcc_amd.device'
+  # a mid-size register through the same path: 20-qubit QFT, read through the alias only
+  qc = circuit.qc('alias20', alias_psi=True)
+  r = qc.reg(20, 0b1011)
+  p = None
+  qc.h(0)
+  p = qc.psi
+  qc.qft(r)
+  ops_, g8 = workloads.qft_stream(range(20)).arrays()
+  want = np.zeros(1 << 20, dtype=np.complex128)
+  want[0b1011] = 1
+  oracle.apply1(want, np.array([1, 1, 1, -1]) / np.sqrt(2), 20, 0)
+  oracle.run_stream(want, 20, ops_, g8)
+  assert np.max(np.abs(p - want)) < 1e-12

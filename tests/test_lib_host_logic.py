@@ -15,9 +15,11 @@ from tests import fake_device
 def cpu_backend():
   tensor.set_tensor_width(128)
   backend.set_device_factory(fake_device.OracleDevice)
+  backend.set_host_mapped_factory(fake_device.OracleDevice)
   backend.set_host_executor(fake_device.OracleHostExecutor())
   yield
   backend.set_device_factory(None)
+  backend.set_host_mapped_factory(None)
   backend.set_host_executor(None)
   tensor.set_tensor_width(None)
 
@@ -188,3 +190,63 @@ def test_complex64_policy():
   qc.h(0); qc.cx(0, 2)
   assert qc.psi.dtype == np.complex64 and qc._dev.bit_width == 64
   assert np.allclose(np.abs(qc.psi) ** 2, [0, 0.5, 0, 0, 0.5, 0, 0, 0], atol=1e-6)
+
+
+def alias_contract(make_qc, oracle_apply):
+  """The reference's in-place contract (src/lib/xgates.cc:37-38; relied on by code that keeps `psi`
+  around): shared by the CPU stand-in test below and tests/test_gpu_lib.py on the real host-mapped state."""
+  qc = make_qc()
+  qc.reg(3, (1, 0, 1))
+  qc.qubit(0.6, 0.8)
+  qc.h(0)
+  p = qc.psi
+  assert p.flags.writeable and qc.psi is p             # one State over one buffer
+  before = np.array(p)
+  qc.h(1)
+  qc.cx(0, 3)
+  want = before.copy()
+  oracle_apply(want, 4, [(None, 1, ops.Hadamard()), (0, 3, ops.PauliX())])
+  assert np.max(np.abs(p - want)) < 1e-12               # the holder of `p` sees the gates
+  # a slice taken earlier aliases too (grover.py:164-style readers)
+  head = p[:4]
+  qc.z(3)
+  oracle_apply(want, 4, [(None, 3, ops.PauliZ())])
+  assert np.max(np.abs(head - want[:4])) < 1e-12
+  # writes through the view are the state
+  p[:] = 0
+  p[5] = 1
+  qc.x(3)
+  assert abs(qc.psi[4] - 1) < 1e-12 and abs(np.vdot(p, p).real - 1) < 1e-12
+  # assignment of a same-size state: the buffer stays THE state
+  other = state.bitstring(1, 1, 0, 0)
+  qc.psi = other
+  assert qc.psi is p and abs(p[12] - 1) < 1e-12
+  # measurement collapses in place
+  qc.h(0)
+  prob, _ = qc.measure_bit(0, 1, collapse=True)
+  assert abs(prob - 0.5) < 1e-12 and abs(abs(p[12]) - 1) < 1e-12 and abs(p[4]) < 1e-12
+  # growing the register makes a new buffer (as `self.psi = self.psi * new` does in circuit.py:121-123);
+  # the old view stays valid memory
+  old = np.array(p)
+  qc.reg(2, 0)
+  assert qc.psi.nbits == 6 and qc.psi is not p
+  assert np.array_equal(np.array(p), old)
+  qc.h(5)
+  assert np.array_equal(np.array(p), old)
+
+
+def test_alias_psi_contract_on_the_stand_in(oracle):
+  def apply(psi, n, gl):
+    for c, t, g in gl:
+      if c is None:
+        oracle.apply1(psi, np.asarray(g).reshape(4), n, t)
+      else:
+        oracle.applyc(psi, np.asarray(g).reshape(4), n, c, t)
+  alias_contract(lambda: circuit.qc('alias', alias_psi=True), apply)
+  # the default stays a read-only snapshot
+  qc = circuit.qc('snap')
+  qc.reg(3, 0)
+  qc.h(0)
+  s0 = qc.psi
+  qc.h(1)
+  assert not s0.flags.writeable and abs(s0[2]) < 1e-15 and abs(qc.psi[2]) > 0.1
