@@ -222,11 +222,11 @@ int qh_timer_end(qh_handle h, float *milliseconds);
 int qh_plan_json(qh_handle h, char *buf, uint64_t cap, uint64_t *needed);
 
 /* The same plan in binary form, complete (ops, phase groups, tables): 3 x u64 (magic
- * 0x51485032, sweeps, gates dropped as no-ops), 64 bytes final_pos (position after the flush of
- * the index bit at each position before it), then per sweep 26 x i64 (rb, regpos[5],
- * regpos_store[5], lanehi[3], nwave, wavepos[2], fixed_ones, ntiles, #ops, #groups, #oterms,
+ * 0x51485033, sweeps, gates dropped as no-ops), 64 bytes final_pos (position after the flush of
+ * the index bit at each position before it), then per sweep 28 x i64 (rb, regpos[6],
+ * regpos_store[6], lanehi[3], nwave, wavepos[2], fixed_ones, ntiles, #ops, #groups, #oterms,
  * #table doubles, #lane tables, lane_low, relayout), 64 bytes dest_pos, 5 x i64 (lanehi and wavepos
- * at store time), 24 x i64 (relayout store as the kernel gets it: reg_dest[5], wave_dest[2], number of
+ * at store time), 25 x i64 (relayout store as the kernel gets it: reg_dest[6], wave_dest[2], number of
  * unit-index runs, 8 masks, 8 shifts), followed by the SweepOp / DGroup / OTerm / table arrays of
  * qcc_amd/csrc/planner.h, each padded to 8 bytes.  For tools and tests that check a plan
  * without a GPU (tests/plan_interp.py executes it with NumPy).                 */

@@ -1042,16 +1042,16 @@ int qh_plan_export(qh_handle h, void *buf, uint64_t cap, uint64_t *needed) {
     out.resize(at + w, 0);
     if (n) memcpy(&out[at], p, n);
   };
-  out.push_back(0x51485032ull);
+  out.push_back(0x51485033ull);
   out.push_back(pr.sweeps.size());
   out.push_back(pr.noop_gates);
   put_bytes(pr.final_pos, 64);
   for (auto &sp : pr.sweeps) {
-    int64_t hdr[26] = {0};
+    int64_t hdr[28] = {0};
     int k = 0;
     hdr[k++] = sp.rb;
-    for (int i = 0; i < 5; ++i) hdr[k++] = sp.regpos[i];
-    for (int i = 0; i < 5; ++i) hdr[k++] = sp.regpos_store[i];
+    for (int i = 0; i < 6; ++i) hdr[k++] = sp.regpos[i];
+    for (int i = 0; i < 6; ++i) hdr[k++] = sp.regpos_store[i];
     for (int i = 0; i < 3; ++i) hdr[k++] = sp.lanehi[i];
     hdr[k++] = sp.nwave;
     for (int i = 0; i < 2; ++i) hdr[k++] = sp.wavepos[i];
@@ -1071,14 +1071,14 @@ int qh_plan_export(qh_handle h, void *buf, uint64_t cap, uint64_t *needed) {
       put_bytes(st, sizeof st);
       // what the kernel is handed for a relayout store: register / wave bit destinations and the runs of
       // unit-index bits (count, then 8 x mask, 8 x shift)
-      int64_t kd[7 + 1 + 2 * qh::kMaxUnitSegs] = {0};
-      for (int i = 0; i < 5; ++i) kd[i] = sp.reg_dest[i];
-      kd[5] = sp.wave_dest[0];
-      kd[6] = sp.wave_dest[1];
+      int64_t kd[8 + 1 + 2 * qh::kMaxUnitSegs] = {0};
+      for (int i = 0; i < 6; ++i) kd[i] = sp.reg_dest[i];
+      kd[6] = sp.wave_dest[0];
+      kd[7] = sp.wave_dest[1];
       uint64_t masks[qh::kMaxUnitSegs] = {0};
       int shifts[qh::kMaxUnitSegs] = {0};
-      kd[7] = sp.relayout ? qh::unit_segments(sp, h->nloc, masks, shifts) : 0;
-      for (int i = 0; i < qh::kMaxUnitSegs; ++i) { kd[8 + i] = (int64_t)masks[i]; kd[8 + qh::kMaxUnitSegs + i] = shifts[i]; }
+      kd[8] = sp.relayout ? qh::unit_segments(sp, h->nloc, masks, shifts) : 0;
+      for (int i = 0; i < qh::kMaxUnitSegs; ++i) { kd[9 + i] = (int64_t)masks[i]; kd[9 + qh::kMaxUnitSegs + i] = shifts[i]; }
       put_bytes(kd, sizeof kd);
     }
     put_bytes(sp.ops.data(), sp.ops.size() * sizeof(qh::SweepOp));

@@ -51,7 +51,8 @@ constexpr int kLaneLow = 3;    // complex128: lane bits 0..2 are ALWAYS index bi
                                // complex64 uses 4 (16 x 8 B): SweepPlan::lane_low
 constexpr int kLaneHi = 3;     // lane bits 3..5 sit on index bits 3,4,5 -- or on any three bits <= kMaxLaneHiBit
 constexpr int kMaxLaneHiBit = 27;  // per-lane byte offset must fit the 32-bit voffset of global_load
-constexpr int kMaxRegBits = 5; // 32 amplitudes (128 VGPRs of data) per lane
+constexpr int kMaxRegBits = 6; // complex128: 5 (32 amplitudes = 128 VGPRs of data per lane); complex64: 6 (64 amplitudes, the same 128 VGPRs)
+inline int max_reg_bits(int bw) { return bw == 128 ? 5 : 6; }
 constexpr int kMaxWaveBits = 2; // index bits selected by the wave id inside a workgroup ("super-tile", see OP_WSWAP)
 constexpr int kMaxSweepOps = 1024;
 constexpr int kMaxInsertBits = 12;  // == kMaxIns of kernels_gate.hip.h (tile enumeration)
@@ -149,7 +150,7 @@ struct SweepPlan {
   uint8_t dest_pos[64] = {0};
   int lanehi_store[kLaneHi] = {3, 4, 5};   // index bits the movable lane bits / wave bits hold when the
   int wavepos_store[kMaxWaveBits] = {0};   // tile is stored (only a relayout sweep may leave them exchanged)
-  int reg_dest[kMaxRegBits] = {6, 7, 8, 9, 10};  // relayout: where register bit k / wave bit j go (positions 6.. of the
+  int reg_dest[kMaxRegBits] = {6, 7, 8, 9, 10, 11};  // relayout: where register bit k / wave bit j go (positions 6.. of the
   int wave_dest[kMaxWaveBits] = {11, 12};        // contiguous block, in ascending order of the index bits they hold)
   std::vector<SweepOp> ops;
   std::vector<DGroup> groups;
@@ -214,7 +215,7 @@ class Planner {
           bool allow_relayout = false)
       : nloc_(nloc), shard_(shard), amp_bytes_(bw == 128 ? 16 : 8), split_lanes_(split_lanes),
         relayout_(allow_relayout) {
-    rb_cap_ = std::min({max_rb, kMaxRegBits, nloc - kLaneBits});
+    rb_cap_ = std::min({max_rb, max_reg_bits(bw), nloc - kLaneBits});
     lane_low_ = bw == 128 ? 3 : 4;   // 128-byte lines: 8 complex128 or 16 complex64 amplitudes
     lane_hi_ = kLaneBits - lane_low_;
     if (wave_bits >= 0) max_wave_ = std::min(wave_bits, kMaxWaveBits);

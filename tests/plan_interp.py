@@ -35,30 +35,30 @@ def export_plan(handle):
   native.check(lib.qh_plan_export(handle, None, 0, ctypes.byref(need)))
   buf = np.zeros(need.value // 8, dtype=np.uint64)
   native.check(lib.qh_plan_export(handle, buf.ctypes.data, need.value, None))
-  assert buf[0] == 0x51485032
+  assert buf[0] == 0x51485033
   nsweeps, noop = int(buf[1]), int(buf[2])
   raw = buf.view(np.uint8)
   final_pos = [int(x) for x in raw[24:88]]
   pos = 88
   sweeps = []
   for _ in range(nsweeps):
-    hdr = raw[pos:pos + 208].view('<i8')
-    pos += 208
-    sp = {'rb': int(hdr[0]), 'regpos': [int(x) for x in hdr[1:6]], 'regpos_store': [int(x) for x in hdr[6:11]],
-          'lanehi': [int(x) for x in hdr[11:14]], 'nwave': int(hdr[14]), 'wavepos': [int(x) for x in hdr[15:17]],
-          'fixed_ones': int(hdr[17]) & (2 ** 64 - 1), 'ntiles': int(hdr[18]), 'n_ltab': int(hdr[23]),
-          'lane_low': int(hdr[24]), 'relayout': int(hdr[25]), 'final_pos': final_pos}
+    hdr = raw[pos:pos + 224].view('<i8')
+    pos += 224
+    sp = {'rb': int(hdr[0]), 'regpos': [int(x) for x in hdr[1:7]], 'regpos_store': [int(x) for x in hdr[7:13]],
+          'lanehi': [int(x) for x in hdr[13:16]], 'nwave': int(hdr[16]), 'wavepos': [int(x) for x in hdr[17:19]],
+          'fixed_ones': int(hdr[19]) & (2 ** 64 - 1), 'ntiles': int(hdr[20]), 'n_ltab': int(hdr[25]),
+          'lane_low': int(hdr[26]), 'relayout': int(hdr[27]), 'final_pos': final_pos}
     sp['dest_pos'] = [int(x) for x in raw[pos:pos + 64]]
     pos += 64
     st = raw[pos:pos + 40].view('<i8')
     pos += 40
     sp['lanehi_store'], sp['wavepos_store'] = [int(x) for x in st[:3]], [int(x) for x in st[3:5]]
-    kd = raw[pos:pos + 192].view('<i8')
-    pos += 192
-    sp['reg_dest'], sp['wave_dest'] = [int(x) for x in kd[:5]], [int(x) for x in kd[5:7]]
-    sp['unit_runs'] = [(int(kd[8 + i]) & (2 ** 64 - 1), int(kd[16 + i])) for i in range(int(kd[7]))]
-    for name, dt, count in (('ops', OP_DT, int(hdr[19])), ('groups', GROUP_DT, int(hdr[20])),
-                            ('oterms', OTERM_DT, int(hdr[21])), ('tables', np.dtype('<f8'), int(hdr[22]))):
+    kd = raw[pos:pos + 200].view('<i8')
+    pos += 200
+    sp['reg_dest'], sp['wave_dest'] = [int(x) for x in kd[:6]], [int(x) for x in kd[6:8]]
+    sp['unit_runs'] = [(int(kd[9 + i]) & (2 ** 64 - 1), int(kd[17 + i])) for i in range(int(kd[8]))]
+    for name, dt, count in (('ops', OP_DT, int(hdr[21])), ('groups', GROUP_DT, int(hdr[22])),
+                            ('oterms', OTERM_DT, int(hdr[23])), ('tables', np.dtype('<f8'), int(hdr[24]))):
       nbytes = count * dt.itemsize
       sp[name] = raw[pos:pos + nbytes].view(dt).copy()
       pos += (nbytes + 7) // 8 * 8
@@ -148,7 +148,7 @@ def run_plan(psi, sweeps, nloc, shard=0):
       tgt = lanepos[tb] if kind == OP_DENSE_LANE else regpos[tb]
       # register controls: bits 0..4 of cm_reg must be one, bits 8..12 zero; thread controls:
       # (index & cm_thread) == cm_thread & ~zero-controls (which travel in n_groups / group_off)
-      pos_reg, neg_reg = np.uint64(int(op['cm_reg']) & 0x1f), np.uint64((int(op['cm_reg']) >> 8) & 0x1f)
+      pos_reg, neg_reg = np.uint64(int(op['cm_reg']) & 0x3f), np.uint64((int(op['cm_reg']) >> 8) & 0x3f)
       cmt = int(op['cm_thread'])
       want = cmt & ~(int(op['n_groups']) | (int(op['group_off']) << 32))
       ok = (in_sweep & ((slot & pos_reg) == pos_reg) & ((slot & neg_reg) == np.uint64(0)) &

@@ -147,9 +147,9 @@ def gen(rb, wide=True):
   batch = min(8, nr)
 
   def tile_io(store):
-    # the store uses its own slot offsets (+0x140) and a base corrected by the index bits
+    # the store uses its own slot offsets (+0x240) and a base corrected by the index bits
     # OP_WSWAP moved between the wave id and the registers (they are not swapped back)
-    blo, bhi, table = ('s24', 's25', 0x140) if store else ('%0', '%1', 0x40)
+    blo, bhi, table = ('s24', 's25', 0x240) if store else ('%0', '%1', 0x40)
     if store:
       # in place: the load address corrected by the index bits OP_WSWAP moved (mask = ~0);
       # relayout sweep: the tile's own contiguous block of the second buffer (mask = 0, the
@@ -214,8 +214,8 @@ def gen(rb, wide=True):
   # that must be 0; bits 8..12 of cm_reg the register bits that must be 0)
   a('s_andn2_b32 s74, s48, s47')
   a('s_andn2_b32 s75, s49, s50')
-  a('s_and_b32 s76, s46, 0x1f')
-  a('s_bfe_u32 s77, s46, 0x50008')
+  a(f's_and_b32 s76, s46, {(1 << rb) - 1:#x}')      # register bits that must be one
+  a(f's_bfe_u32 s77, s46, {(rb << 16) | 8:#x}')      # ... that must be zero (bits 8.. of cm_reg)
   a(f'v_and_b32 v{V_A}, s48, %6')
   a(f'v_and_b32 v{V_B}, s49, %7')
   a(f'v_cmp_eq_u32 vcc, s74, v{V_A}')
@@ -1040,6 +1040,20 @@ def gen(rb, wide=True):
   tile_io(store=True)
   a('s_nop 0')
 
+  # s_branch / s_cbranch reach +-32 Ki dwords (128 KiB).  The complex64 RB=6 island is ~180 KiB of code:
+  # its op sections are laid out on BOTH sides of the dispatcher (entry jumps over the first half), so
+  # that every section is within reach of L_op / L_next / L_done and of the sections it jumps into.
+  if len(a.lines) > 20000:
+    lab = lambda nm: a.lines.index(f'{nm}_%=:')
+    i_op, i_sec, i_done = lab('L_op'), lab('L_reg0'), lab('L_done')
+    tops = [lab(nm) for nm in ('L_real', 'L_rrc0', 'L_lane_real', 'L_bf', 'L_bfl', 'L_lswap', 'L_wswap', 'L_dpp', 'L_lrd',
+                               'L_lane', 'L_diag')]
+    mid = (i_sec + i_done) // 2
+    cut = min((i for i in tops if i >= mid), default=tops[-1])
+    assert a.lines[cut - 1].startswith('s_branch '), 'the section before the cut must not fall through'
+    assert a.lines[i_sec - 1].startswith('s_branch ') and i_op < i_sec < cut < i_done
+    a.lines = ([f's_branch {L("L_entry")}'] + a.lines[i_sec:cut] + [f'{L("L_entry")}:'] + a.lines[:i_sec] +
+               a.lines[cut:])
   clob = ([f'v{i}' for i in range(TEMP_LO, T0 + 2 * W() * nr)] + [f's{i}' for i in range(16, 28)] + [f's{i}' for i in range(36, 100)] +
           ['vcc', 'scc', 'memory'])
   names = {'0': 'blo', '1': 'bhi', '2': 'prm', '3': 'tidx', '4': 'voff', '5': 'lane', '6': 'itlo', '7': 'ithi',
@@ -1059,7 +1073,7 @@ def gen(rb, wide=True):
 def main():
   out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'qcc_amd', 'csrc')
   for wide in (True, False):
-    for rb in (2, 3, 4, 5):
+    for rb in (2, 3, 4, 5) + (() if wide else (6,)):     # complex64: 64 amplitudes per lane fit the same 128 VGPRs
       path = os.path.join(out, f'sweep_island_rb{rb}.inc' if wide else f'sweep_island_f32_rb{rb}.inc')
       with open(path, 'w') as f:
         f.write(gen(rb, wide))
