@@ -32,6 +32,14 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def default_qubits(world):
+  """BASELINE.json: config 2 (30 qubits) on one GPU; config 5's ladder on several -- 34 / 35 / 36 qubits on
+  2 / 4 / 8 GPUs, 2^33 amplitudes = 128 GiB per GPU."""
+  g = int(math.log2(world))
+  assert 1 << g == world, 'number of GPUs must be a power of two'
+  return 30 if world == 1 else 33 + g
+
+
 def parse():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
@@ -230,7 +238,7 @@ def main():
     local_rank %= native.device_count()
   gbits = int(math.log2(world))
   assert 1 << gbits == world, 'number of GPUs must be a power of two'
-  n = args.qubits or (30 if world == 1 else 33 + gbits)
+  n = args.qubits or default_qubits(world)
   nloc = n - gbits
   args.qubits_shard = nloc
   fusion = args.fusion if args.fusion >= 0 else native.QH_FUSE_SWEEP
