@@ -43,8 +43,8 @@ def default_qubits(world):
 def parse():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
-  ap.add_argument('--steps', type=int, default=5)
-  ap.add_argument('--warmup', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=10)
+  ap.add_argument('--warmup', type=int, default=3)   # (the second step after a cold start still runs 5% slow)
   ap.add_argument('--qubits', type=int, default=0,
                   help='default: 30 on one GPU (BASELINE config 2); 33 + log2(gpus) on several (config 5 ladder)')
   ap.add_argument('--no-ladder-base', action='store_true', help='N=1: skip the extra 33-qubit measurement')
