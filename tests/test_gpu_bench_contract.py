@@ -1,0 +1,47 @@
+"""bench.py end to end on the GPU at a small size: one JSON line with the contract's keys, the
+roofline and cpu_baseline objects, and the sharded code path with a world of one."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*args, env=None):
+  e = dict(os.environ)
+  e.update(env or {})
+  r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), *args], capture_output=True, text=True, timeout=900,
+                     cwd=ROOT, env=e)
+  assert r.returncode == 0, r.stderr[-2000:]
+  lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+  assert len(lines) == 1, r.stdout[-1000:]
+  return json.loads(lines[0])
+
+
+def test_bench_line_small():
+  d = _run('--qubits', '24', '--steps', '3', '--warmup', '2', '--cpu-qubits', '24', '--cpu-gates', '6')
+  for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+            'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+    assert k in d, k
+  assert d['n_gpus'] == 1 and d['steps'] == 3 and d['warmup'] == 2 and d['dtype'] == 'f64' and d['vs_baseline'] is None
+  assert d['config']['qubits'] == 24 and 'workload' in d['config'] and 'model' not in d['config']
+  r = d['roofline']
+  assert r['bound'] == 'hbm' and r['peak'] == 8000.0 and r['unit'] == 'GB/s' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12
+  assert r['bytes_per_launch'] == 2 * 16 * 2 ** 24
+  c = d['cpu_baseline']
+  assert c['cores'] == 1 and c['kind'] in ('reference', 'port') and c['value'] > 0 and len(c['binary_sha16']) == 16
+  assert c['all_cores']['cores'] >= 1 and c['all_cores']['value'] > 0
+  assert abs(d['norm2'] - 1) < 1e-10
+  # value = gates x steps x (2^n / 2^30) / wall
+  assert abs(d['value'] - 300 * 3 * 2 ** (24 - 30) / (d['ms_per_step'] * 3e-3)) / d['value'] < 1e-6
+  assert 'cached_plan' in d and d['cached_plan']['ms_per_step'] > 0
+
+
+def test_bench_sharded_world_of_one():
+  d = _run('--sharded', '--qubits', '22', '--steps', '2', '--warmup', '1', '--no-cpu-baseline', env={'QCC_EXCHANGE': 'native'})
+  assert d['n_gpus'] == 1 and d['exchange_path'] == 'rccl' and d['exchanges_per_step'] == 0
+  assert abs(d['norm2'] - 1) < 1e-10
