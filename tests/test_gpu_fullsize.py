@@ -75,3 +75,32 @@ def test_config4_grover_34q_one_iteration():
       assert abs(st.amplitude((xx << nb) | anc | 5)) < 1e-14
     s = st.stats()
     assert s['gates_submitted'] == len(ops)
+
+
+@pytest.mark.parametrize('n,bw', [(31, 128), (32, 128), (31, 64), (33, 128)])
+def test_qft_between_the_configs_closed_form(n, bw):
+  """31 / 32 / 33-qubit QFT on one GPU (plans with two wave bits, relayout between two 32-128 GiB buffers,
+  64-bit indices past the reference's 30-qubit limit): closed form on sampled amplitudes, norm, and the
+  inverse circuit on the re-laid-out state returns the basis state."""
+  ops, g8 = workloads.qft_stream(range(n)).arrays()
+  x = 0x1B2CB9A5E3 & ((1 << n) - 1)
+  try:
+    st = device.DeviceState(n, bw, fusion=native.QH_FUSE_SWEEP)
+  except native.QhError as e:
+    if e.code == native.QH_ERR_NOMEM:
+      pytest.skip(str(e))
+    raise
+  tol = 1e-10 if bw == 128 else 2e-6
+  with st:
+    st.init_basis(x)
+    st.run_stream(ops, g8)
+    assert abs(st.norm2() - 1.0) < (1e-9 if bw == 128 else 1e-4)
+    rng = np.random.default_rng(n)
+    idx = [0, (1 << n) - 1] + [int(v) for v in rng.integers(0, 1 << n, size=40)]
+    want = workloads.qft_analytic(n, x, idx)
+    got = np.array([st.amplitude(i) for i in idx])
+    assert np.max(np.abs(got - want)) <= tol
+    st.run_stream(*_inverse(ops, g8))
+    i, p = st.argmax()
+    assert i == x and abs(p - 1.0) < (1e-9 if bw == 128 else 1e-4)
+    assert abs(st.amplitude(x) - 1.0) < (1e-9 if bw == 128 else 1e-4)
