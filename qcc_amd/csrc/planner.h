@@ -800,61 +800,34 @@ class Planner {
 
   struct PTerm { uint64_t mask; double re, im; };
 
-  // How many lane butterflies leave the LDS (ds_bpermute) path, by lane-bit class.
+  // How many lane butterflies leave the LDS (ds_bpermute) path, by lane-bit class: lane bits 0, 1 and 3
+  // reach their partner with ONE DPP move per dword (quad_perm, row_ror:8: "01"), lane bit 2 needs two ("23").
   struct LaneChoice { int dpp01 = 0, dpp23 = 0, lswap = 0, real01 = 0, real23 = 0; };
+  static bool one_step_dpp(uint32_t lane_bit) { return lane_bit < 2 || lane_bit == 3; }
 
-  // ds_bpermute_b32 issues once per ~6.1 cycles per CU (tools/membench/bpermbench: the LDS
-  // pipe is shared by the four SIMDs), a VALU instruction once per ~1.18.  A sweep with many
-  // lane-bit gates is therefore bound by the LDS pipe long before HBM (supremacy: 21 lane
-  // ops -> 15 ms for a 6 ms sweep).  Lane butterflies can instead fetch the partner by DPP
-  // moves (lane bits 0..3) or exchange lane bit 4/5 with a register bit by
-  // v_permlane{16,32}_swap and run as register butterflies: more VALU work, no LDS.  The
-  // split is chosen per sweep so that neither pipe exceeds the other (cycles per tile per CU).
+  // ds_bpermute_b32 issues once per ~6.1 cycles per CU (tools/membench/bpermbench: the LDS pipe is shared
+  // by the four SIMDs and their twelve waves).  Lane butterflies can instead fetch the partner by DPP moves
+  // (lane bits 0..3) or exchange lane bit 4/5 with a register bit by v_permlane{16,32}_swap and run as
+  // register butterflies: more VALU instructions, no LDS.  What decides is not the pipes' throughput but the
+  // LATENCY of a wave's op stream: with three waves per SIMD a sweep takes (wave lifetime per tile) x 171
+  // tiles, and under this load the clock drops to 1.7-2.1 GHz.  Measured inside the kernel (s_memtime per op,
+  // tools/probes/prof_island.sh): a bpermute butterfly keeps its wave for 3 200-7 700 cycles when the other
+  // eleven waves of the CU queue at the same pipe, a DPP one for 1 300-3 000, swap + register butterfly for
+  // 1 800-2 500.  So a sweep whose LDS pipe would be busy for more than QH_LDS_FLOOR cycles per tile
+  // (default 3 500: half of the HBM time of a tile) moves ALL its lane butterflies to the VALU; lighter
+  // sweeps (a QFT's second and third: three lane targets) are HBM-bound either way and keep the LDS path,
+  // which draws less power (30-qubit QFT first sweep 6.7 -> 6.35 ms, supremacy 47.9 -> 47.1, QFT-33 159 -> 153).
   LaneChoice choose_lane_paths(const SweepPlan &sp) const {
-    const double kLds = 6.1 * (amp_bytes_ == 16 ? 128 : 64), kValu = 1.18;
+    const double kLds = 6.1 * (amp_bytes_ == 16 ? 128 : 64);
     const double dw = amp_bytes_ == 16 ? 1.0 : 0.5;
-    double lds = 0, valu = 0;
-    int n01 = 0, n23 = 0, n45 = 0, r01 = 0, r23 = 0;
+    double lds = 0;
     for (const SweepOp &o : sp.ops) {
-      if (o.kind == OP_WSWAP) { lds += 256 * dw; continue; }   // 16 ds_write_b128 + 16 ds_read_b128, 8 cycles each
-      if (o.kind == OP_LSWAP) { valu += 128 * dw; continue; }
-      if (o.kind == OP_DIAG) {
-        bool c_part = false;
-        for (uint32_t gi = 0; gi < o.n_groups; ++gi) {
-          const DGroup &g = sp.groups[o.group_off + gi];
-          const int pc = popc(g.reg_mask);
-          valu += 24 + 12.0 * g.ntab + (pc == 0 ? 4 : (128 >> pc));
-          c_part |= pc == 0;
-        }
-        if (c_part && !(o.flags & OPF_DEFER_C)) valu += 128;
-        continue;
-      }
-      const bool lane = o.kind == OP_DENSE_LANE;
-      if (lane) lds += kLds;
-      if (o.flags & OPF_BFLY) {
-        valu += 64;
-        if (lane) (o.tb < 2 ? n01 : o.tb < 4 ? n23 : n45)++;
-      } else if (o.flags & OPF_REAL) {
-        valu += lane ? 128 : 160;
-        if (lane && !(o.flags & OPF_USE_C) && o.tb < 4) (o.tb < 2 ? r01 : r23)++;
-      } else valu += lane ? 384 : 400;
+      if (o.kind == OP_WSWAP) lds += 256 * dw;      // 16 ds_write_b128 + 16 ds_read_b128, 8 cycles each
+      else if (o.kind == OP_DENSE_LANE) lds += kLds;
     }
-    valu *= kValu;
+    static const double floor_cycles = env_int("QH_LDS_FLOOR", 3500);
     LaneChoice ch;
-    const double floor_cycles = 5500;           // ~0.8 x the HBM time of a tile (6 ms sweep, 2048 tiles per CU)
-    auto take = [&](int *have, int *out, double add_instr) {
-      while (*have > 0 && lds > std::max(valu, floor_cycles) && valu + add_instr * kValu * dw < lds) {
-        lds -= kLds;
-        valu += add_instr * kValu * dw;
-        --*have;
-        ++*out;
-      }
-    };
-    take(&n01, &ch.dpp01, 128);                 // 4 DPP moves per slot
-    take(&r01, &ch.real01, 128);                // real (x, cx, ry ...) lane ops: same fetch, same combine
-    take(&n45, &ch.lswap, 256);                 // swap in + swap out, 64 double-rate instructions each
-    take(&n23, &ch.dpp23, 256);                 // 8 DPP moves per slot
-    take(&r23, &ch.real23, 256);
+    if (lds > floor_cycles) ch.dpp01 = ch.dpp23 = ch.lswap = ch.real01 = ch.real23 = 1 << 20;
     return ch;
   }
 
@@ -1042,7 +1015,7 @@ class Planner {
           memset(op.g, 0, sizeof op.g);
           if (bv == 1) { op.g[0] = -1.0; op.g[1] = 1.0; }        // LDS lane form: new = own + beta*partner,
           else if (bv == 2) { op.g[0] = 1.0; op.g[1] = -1.0; }   // beta on the 0-lane / on the 1-lane
-          int *budget = (li >= 0 && li < 2) ? &ch.dpp01 : (li >= 2 && li < 4) ? &ch.dpp23 : nullptr;
+          int *budget = (li < 0 || li >= 4) ? nullptr : one_step_dpp((uint32_t)li) ? &ch.dpp01 : &ch.dpp23;
           if (budget && *budget > 0) {
             // DPP path: new.re = own.re + b_re*q.re, new.im = own.im + b_im*q.im with q the partner
             // (re/im exchanged for v, v^+); g = b_re(0-lane), b_re(1-lane), b_im(0-lane), b_im(1-lane).
@@ -1058,7 +1031,7 @@ class Planner {
           }
         }
         if (bv < 0 && (op.flags & OPF_REAL) && op.kind == OP_DENSE_LANE && op.tb < 4) {
-          int *budget = op.tb < 2 ? &ch.real01 : &ch.real23;   // real lane op: partner by DPP instead of LDS
+          int *budget = one_step_dpp(op.tb) ? &ch.real01 : &ch.real23;   // real lane op: partner by DPP instead of LDS
           if (*budget > 0) {
             --*budget;
             op.flags |= OPF_LANE_DPP;

@@ -36,6 +36,10 @@ import sys
 NT = '' if os.environ.get('QH_ISLAND_NT', '1') == '0' else ' nt'
 T0 = 40
 TEMP_LO, TEMP_HI = 16, 39
+# QH_ISLAND_PROF=1: a measurement build of the complex128 RB=5 island (sweep_island_prof_rb5.inc, compiled
+# only with -DQH_PROF, tools/probes/prof_island.sh): sampled waves write s_memtime at the start, after the
+# tile has arrived, at the head of every op, after the stores are issued and after they have completed.
+PROF = os.environ.get('QH_ISLAND_PROF') == '1'
 
 
 class DT:
@@ -140,11 +144,39 @@ def cmul_vv(a, xr, xi, fr, fi, tmp):
   a(FMA() + f' {xr}, {xr}, {fr}, -{tmp}')
 
 
-def gen(rb, wide=True):
+def gen(rb, wide=True, prof=False):
   DT.wide = wide
   nr = 1 << rb
   a = Asm()
   batch = min(8, nr)
+  nrec = [0]
+
+  def prof_rec(wait_stores=False, real_at=None):
+    """s[30:31] = this wave's row of the profile buffer (0: not sampled), s101 = byte offset of the next record."""
+    if not prof:
+      return
+    nrec[0] += 1
+    skip = f'L_prof{nrec[0]}'
+    a('s_cmp_eq_u64 s[30:31], 0')
+    a(f's_cbranch_scc1 {L(skip)}')
+    if wait_stores:
+      a('s_waitcnt vmcnt(0)')
+    a('s_memtime s[28:29]')
+    a('s_waitcnt lgkmcnt(0)')
+    a('v_mov_b32 v30, s28')
+    a('v_mov_b32 v31, s29')
+    a('v_mov_b32 v32, s101')
+    a('global_store_dwordx2 v32, v[30:31], s[30:31]')
+    a('s_add_u32 s101, s101, 8')
+    a('s_and_b32 s101, s101, 0x3ff')              # 128 records per row
+    if real_at is not None:                       # the 100 MHz counter beside it: records 126 / 127 of the row
+      a('s_memrealtime s[28:29]')
+      a('s_waitcnt lgkmcnt(0)')
+      a('v_mov_b32 v30, s28')
+      a('v_mov_b32 v31, s29')
+      a(f'v_mov_b32 v32, {real_at * 8}')
+      a('global_store_dwordx2 v32, v[30:31], s[30:31]')
+    a.label(skip)
 
   def tile_io(store):
     # the store uses its own slot offsets (+0x240) and a base corrected by the index bits
@@ -178,6 +210,10 @@ def gen(rb, wide=True):
           a(f'global_load_{dw} {regs}, %4, s[98:99]' + NT)
 
   # ---- prologue: parameters, then one 1-KiB global_load_dwordx4 per slot ------------
+  if prof:
+    a('s_mov_b64 s[30:31], %[prow]')
+    a('s_mov_b32 s101, 0')
+    prof_rec(real_at=126)
   a('s_load_dwordx4 s[36:39], %2, 0x0')   # ops cursor, groups base
   a('s_load_dwordx2 s[40:41], %2, 0x10')  # oterms base
   a('s_load_dwordx2 s[42:43], %2, 0x18')  # s42 = ops remaining, s43 = tables - groups (bytes)
@@ -185,29 +221,60 @@ def gen(rb, wide=True):
   a('s_mov_b64 s[26:27], %3')                     # tile index at load time (see the store)
   a('s_load_dwordx8 s[16:23], s[36:37], 0x0')     # header of the first op
   a('s_waitcnt vmcnt(0)')
+  prof_rec()
 
   # ---- op loop ----------------------------------------------------------------------
   # The 32-byte op header (kind tb cm_reg n_groups cm_thread(2) group_off flags) of op i+1 is
   # fetched into s[16:23] while op i runs: the scalar-load latency (hundreds of cycles behind
   # the tile stream) is off the critical path.  The 64-byte matrix g[8] is loaded only by the
   # op kinds that read it (most ops of a QFT or supremacy sweep do not).
+  # Dispatch: the host puts a handler number into the upper half of `kind` (planner.h op_handler_id);
+  # s[24:25] holds the address of a table of s_branch instructions, one per handler.  A taken branch
+  # costs a wave ~50 cycles (the instruction buffer refills), and the compare-and-branch chains this
+  # replaces took 3-5 of them per op plus 5-10 not-taken ones: ~400 cycles of the ~650 a 64-instruction
+  # register butterfly held its wave (tools/probes/prof_island.sh).  Every handler ends with its own copy
+  # of the loop head (next_op), so an op costs two jumps: s_setpc_b64 into the table, s_branch to the code.
+  # The op list ends with a sentinel whose handler is the store (HID_DONE): no counter, no end test.
+  HID_DIAG, HID_DENSE, HID_WSWAP, HID_BFL, HID_DPP, HID_DONE, HID_LSWAP, HID_BFREG, NHID = 0, 1, 2, 3, 4, 5, 8, 24, 64
+
+  def op_head():
+    prof_rec()
+    a('s_waitcnt lgkmcnt(0)')
+    a('s_mov_b64 s[44:45], s[16:17]')
+    a('s_mov_b64 s[46:47], s[18:19]')
+    a('s_mov_b64 s[48:49], s[20:21]')
+    a('s_mov_b64 s[50:51], s[22:23]')
+    a('s_load_dwordx8 s[16:23], s[36:37], 0x60')   # next op's header (the buffer is padded: reading one past the end is harmless)
+    a('s_lshr_b32 s74, s44, 16')                   # handler number
+    a('s_and_b32 s44, s44, 0xffff')                # kind
+    a('s_lshl_b32 s74, s74, 2')
+    a('s_add_u32 s72, s24, s74')
+    a('s_addc_u32 s73, s25, 0')
+    a('s_setpc_b64 s[72:73]')
+
+  def next_op():
+    a('s_mov_b64 exec, -1')                     # (waves are always full: 64 x k threads per block)
+    a('s_add_u32 s36, s36, 96')
+    a('s_addc_u32 s37, s37, 0')
+    op_head()
+
+  targets = ['L_next'] * NHID
+  targets[HID_DIAG], targets[HID_DENSE], targets[HID_WSWAP] = 'L_diag', 'L_dense', 'L_wswap'
+  targets[HID_BFL], targets[HID_DPP], targets[HID_DONE] = 'L_bfl_e', 'L_dpp', 'L_done'
+  for r in range(rb):
+    targets[HID_LSWAP + 2 * r], targets[HID_LSWAP + 2 * r + 1] = f'L_lswap16_r{r}', f'L_lswap32_r{r}'
+  for v in range(5):
+    for b in range(rb):
+      targets[HID_BFREG + 8 * v + b] = f'L_bf{v}_{b}'
+  a('s_getpc_b64 s[24:25]')                     # address of the next instruction; the table starts 12 bytes on
+  a('s_add_u32 s24, s24, 12')
+  a('s_addc_u32 s25, s25, 0')
+  a(f's_branch {L("L_op")}')
+  for t in targets:
+    a(f's_branch {L(t)}')
   a.label('L_op')
-  a('s_cmp_eq_u32 s42, 0')
-  a(f's_cbranch_scc1 {L("L_done")}')
-  a('s_waitcnt lgkmcnt(0)')
-  a('s_mov_b64 s[44:45], s[16:17]')
-  a('s_mov_b64 s[46:47], s[18:19]')
-  a('s_mov_b64 s[48:49], s[20:21]')
-  a('s_mov_b64 s[50:51], s[22:23]')
-  a('s_load_dwordx8 s[16:23], s[36:37], 0x60')   # next op's header (the buffer is padded: reading one past the end is harmless)
-  a('s_cmp_eq_u32 s44, 2')
-  a(f's_cbranch_scc1 {L("L_diag")}')
-  a('s_cmp_eq_u32 s44, 3')                    # OP_LSWAP: exchange lane bit 4/5 with a register bit
-  a(f's_cbranch_scc1 {L("L_lswap")}')
-  a('s_cmp_eq_u32 s44, 4')                    # OP_WSWAP: exchange a wave bit with a register bit (through LDS)
-  a(f's_cbranch_scc1 {L("L_wswap")}')
-  a('s_bitcmp1_b32 s51, 3')                   # OPF_BFLY: uncontrolled unit-entry butterfly
-  a(f's_cbranch_scc1 {L("L_bf")}')
+  op_head()
+  a.label('L_dense')
   a('s_load_dwordx16 s[52:67], s[36:37], 0x20')  # g[8]
   # control predicate of this thread: (it & cm_thread) == cm_thread  -> s[68:69]
   # (zero-controls: header words n_groups / group_off of a dense op hold the bits of cm_thread
@@ -241,7 +308,7 @@ def gen(rb, wide=True):
   for b in range(rb):
     a(f's_cmp_eq_u32 s45, {b}')
     a(f's_cbranch_scc1 {L(f"L_rrc{b}")}')
-  a(f's_branch {L("L_next")}')
+  next_op()
   a.label('L_generic')
   a('s_cmp_eq_u32 s44, 1')
   a(f's_cbranch_scc1 {L("L_lane")}')
@@ -249,11 +316,7 @@ def gen(rb, wide=True):
     a(f's_cmp_eq_u32 s45, {b}')
     a(f's_cbranch_scc1 {L(f"L_reg{b}")}')
   a.label('L_next')
-  a('s_mov_b64 exec, -1')                     # (waves are always full: 64 x k threads per block)
-  a('s_add_u32 s36, s36, 96')
-  a('s_addc_u32 s37, s37, 0')
-  a('s_sub_u32 s42, s42, 1')
-  a(f's_branch {L("L_op")}')
+  next_op()
 
   # ---- dense 2x2 on register bit b: in-place butterflies ----------------------------
   gnames = ['g0r', 'g0i', 'g1r', 'g1i', 'g2r', 'g2i', 'g3r', 'g3i']
@@ -304,7 +367,7 @@ def gen(rb, wide=True):
       a(MOV() + f' {bi}, {t3}')
       a('s_mov_b64 exec, s[70:71]')
       a.label(skip)
-    a(f's_branch {L("L_next")}')
+    next_op()
 
   # ---- REAL uncontrolled dense ops: half the arithmetic, results in place ---------------
   a.label('L_real')
@@ -313,7 +376,7 @@ def gen(rb, wide=True):
   for b in range(rb):
     a(f's_cmp_eq_u32 s45, {b}')
     a(f's_cbranch_scc1 {L(f"L_rr{b}")}')
-  a(f's_branch {L("L_next")}')
+  next_op()
   for b in range(rb):
     a.label(f'L_rr{b}')
     load_matrix_f32()
@@ -339,7 +402,7 @@ def gen(rb, wide=True):
       for (k0, k1), (ta, tb) in zip(grp, tmps):
         a(MOV() + f' {X(k0)}, {ta}')
         a(MOV() + f' {Y(k0)}, {tb}')
-    a(f's_branch {L("L_next")}')
+    next_op()
   def lane_pipeline(first_buf, depth, combine_slot):
     """Partner values of slot k arrive by ds_bpermute `depth` slots ahead of their use
     (the shuffle latency, not its issue rate, bounds a lane op: SQ_WAIT_INST_LDS was 42%
@@ -386,7 +449,7 @@ def gen(rb, wide=True):
       a(MOV() + f' {X(k0)}, {ta}')
       a(MOV() + f' {Y(k0)}, {tb_}')
       a.label(skip)
-    a(f's_branch {L("L_next")}')
+    next_op()
 
   # lane bit, real: new = ca*mine + cb*other with real per-lane ca, cb -- 4 FP64 ops per slot
   a.label('L_lane_real')
@@ -432,29 +495,16 @@ def gen(rb, wide=True):
   a('s_cmp_eq_u32 s46, 0')
   a(f's_cbranch_scc0 {L("L_lane_real_cc")}')
   lane_pipeline(24, 4, comb_real)
-  a(f's_branch {L("L_next")}')
+  next_op()
   a.label('L_lane_real_cc')
   lane_pipeline(24, 4, comb_real_c)              # (all slots are shuffled: the pipeline's wait counts stay static)
-  a(f's_branch {L("L_next")}')
+  next_op()
 
   # ---- unit-entry butterflies (OPF_BFLY): the gate is c*M with M's entries in {1,-1,i,-i};
   # the planner moved c into another op of the sweep, so M costs adds only, in place.
   #   variant (flags bits 4..6): 0  [[1, 1],[ 1,-1]]  (h)        1  [[1,-1],[1,1]]  (yroot)
   #   2  [[1,1],[-1,1]] (yroot^+)   3  [[1,-i],[-i,1]] (v, sqrt-x)   4  [[1,i],[i,1]] (v^+)
-  a.label('L_bf')
-  a('s_bfe_u32 s74, s51, 0x30004')
-  a('s_cmp_eq_u32 s44, 1')
-  a(f's_cbranch_scc1 {L("L_bfl")}')
-  for v in range(5):
-    a(f's_cmp_eq_u32 s74, {v}')
-    a(f's_cbranch_scc1 {L(f"L_bfv{v}")}')
-  a(f's_branch {L("L_next")}')
-  for v in range(5):
-    a.label(f'L_bfv{v}')
-    for b in range(rb):
-      a(f's_cmp_eq_u32 s45, {b}')
-      a(f's_cbranch_scc1 {L(f"L_bf{v}_{b}")}')
-    a(f's_branch {L("L_next")}')
+  a.label('L_bf')                               # (section marker; handlers are reached through the table)
   for v in range(5):
     for b in range(rb):
       a.label(f'L_bf{v}_{b}')
@@ -499,8 +549,10 @@ def gen(rb, wide=True):
           for k0, k1 in grp:
             a(FMA() + f' {Y(k1)}, 2.0, {Y(k1)}, {X(k0)}')    # bi' = bi + ar = 2bi + ar'
             a(FMA() + f' {X(k1)}, 2.0, {X(k1)}, -{Y(k0)}')   # br' = br - ai = 2br - ai'
-      a(f's_branch {L("L_next")}')
+      next_op()
   # lane bit: partner p via ds_bpermute, own value o
+  a.label('L_bfl_e')
+  a('s_bfe_u32 s74, s51, 0x30004')            # butterfly variant
   a.label('L_bfl')
   a('s_bitcmp1_b32 s51, 7')                   # OPF_LANE_DPP: partner values by DPP moves (VALU), not LDS
   a(f's_cbranch_scc1 {L("L_dpp")}')
@@ -513,7 +565,7 @@ def gen(rb, wide=True):
   for v, lab in ((0, 'L_bfl_a'), (1, 'L_bfl_b'), (2, 'L_bfl_b'), (3, 'L_bfl_v'), (4, 'L_bfl_w')):
     a(f's_cmp_eq_u32 s74, {v}')
     a(f's_cbranch_scc1 {L(lab)}')
-  a(f's_branch {L("L_next")}')
+  next_op()
 
   def bf_lane(form):
     def comb(k, pr, pi):
@@ -530,7 +582,7 @@ def gen(rb, wide=True):
         a(ADDS(X(k), X(k), pi, neg=True))
         a(ADDS(Y(k), Y(k), pr))
     lane_pipeline(20, 4, comb)
-    a(f's_branch {L("L_next")}')
+    next_op()
 
   c0 = LN_COEF['car']
   a.label('L_bfl_a')                               # h: alpha = +1 on the 0-lane, -1 on the 1-lane
@@ -569,15 +621,8 @@ def gen(rb, wide=True):
   # bit r and the old register bit r is the lane bit.  The planner emits the gate as a
   # register op in between and swaps back (the op is an involution).  No LDS traffic:
   # ds_bpermute issues once per ~6 cycles per CU, these run at VALU rate.
-  a.label('L_lswap')
+  a.label('L_lswap')                            # (section marker)
   for r in range(rb):
-    a(f's_cmp_eq_u32 s46, {r}')
-    a(f's_cbranch_scc1 {L(f"L_lswap_r{r}")}')
-  a(f's_branch {L("L_next")}')
-  for r in range(rb):
-    a.label(f'L_lswap_r{r}')
-    a('s_cmp_eq_u32 s45, 5')
-    a(f's_cbranch_scc1 {L(f"L_lswap32_r{r}")}')
     for name, ins in ((f'L_lswap16_r{r}', 'v_permlane16_swap_b32'), (f'L_lswap32_r{r}', 'v_permlane32_swap_b32')):
       a.label(name)
       for k in range(nr):
@@ -585,7 +630,7 @@ def gen(rb, wide=True):
           continue
         for d in range(2 * W()):
           a(f'{ins} v{T(k) + d}, v{T(k | (1 << r)) + d}')
-      a(f's_branch {L("L_next")}')
+      next_op()
 
   # ---- OP_WSWAP: wave bit tb <-> register bit r (header field cm_reg) --------------------
   # The 2^W waves of a workgroup hold the tiles of ONE super-tile: they differ in W chosen
@@ -618,7 +663,7 @@ def gen(rb, wide=True):
   for r in range(rb):
     a(f's_cmp_eq_u32 s46, {r}')
     a(f's_cbranch_scc1 {L(f"L_wswap_r{r}")}')
-  a(f's_branch {L("L_next")}')
+  next_op()
   for r in range(rb):
     a.label(f'L_wswap_r{r}')
     a('s_cmp_eq_u32 s74, 0')
@@ -637,12 +682,12 @@ def gen(rb, wide=True):
         a('s_waitcnt lgkmcnt(0)')
         a('s_barrier')
       if parity == 1:
-        a(f's_branch {L("L_next")}')                # bit 0: index bits unchanged (both positions hold 0)
+        next_op()                # bit 0: index bits unchanged (both positions hold 0)
       else:
         a('s_xor_b64 %3, %3, s[48:49]')
         a('v_xor_b32 %6, s48, %6')
         a('v_xor_b32 %7, s49, %7')
-        a(f's_branch {L("L_next")}')
+        next_op()
 
   # ---- butterfly on lane bit 0..3 with DPP partner fetch (OPF_LANE_DPP) -------------------
   # new.re = o.re + beta_re * q.re ; new.im = o.im + beta_im * q.im, q = partner value, or the
@@ -673,9 +718,9 @@ def gen(rb, wide=True):
   for code in range(8):
     a(f's_cmp_eq_u32 s75, {code}')
     a(f's_cbranch_scc1 {L(f"L_dpp{code}")}')
-  a(f's_branch {L("L_next")}')
+  next_op()
   DPP1 = {0: ['quad_perm:[1,0,3,2]'], 1: ['quad_perm:[2,3,0,1]'],
-          2: ['row_half_mirror', 'quad_perm:[3,2,1,0]'], 3: ['row_mirror', 'row_half_mirror']}
+          2: ['row_half_mirror', 'quad_perm:[3,2,1,0]'], 3: ['row_ror:8']}
   for code in range(8):
     tbv, exch = code & 3, code >> 2
     a.label(f'L_dpp{code}')
@@ -699,7 +744,7 @@ def gen(rb, wide=True):
           a(f'v_mov_b32_dpp v{Q + d}, v{TQ + d} {steps[1]} row_mask:0xf bank_mask:0xf')
       a(FMA() + f' {X(k)}, {bre}, {V2(Q)}, {X(k)}')
       a(FMA() + f' {Y(k)}, {bim}, {V2(Q + W())}, {Y(k)}')
-    a(f's_branch {L("L_next")}')
+    next_op()
 
 
   # ---- real 2x2 on lane bit 0..3, partner by DPP moves (OPF_LANE_DPP on a REAL lane op) ------
@@ -735,7 +780,7 @@ def gen(rb, wide=True):
   for tbv in range(4):
     a(f's_cmp_eq_u32 s45, {tbv}')
     a(f's_cbranch_scc1 {L(f"L_lrd{tbv}")}')
-  a(f's_branch {L("L_next")}')
+  next_op()
   ca2, cb2 = V2(CA), V2(CB)
   for tbv in range(4):
     a.label(f'L_lrd{tbv}')
@@ -764,7 +809,7 @@ def gen(rb, wide=True):
       a(FMA() + f' {X(k)}, {cb2}, {V2(Q2)}, {X(k)}')
       a(FMA() + f' {Y(k)}, {cb2}, {V2(Q2 + W())}, {Y(k)}')
       a.label(skip)
-    a(f's_branch {L("L_next")}')
+    next_op()
 
   # ---- dense 2x2 on a lane bit: partner via ds_bpermute -------------------------------
   a.label('L_lane')
@@ -843,7 +888,7 @@ def gen(rb, wide=True):
     else:
       a('s_waitcnt lgkmcnt(0)')
     combine(k, LN_BUF[k & 1])
-  a(f's_branch {L("L_next")}')
+  next_op()
   a.label('L_lane_ctl')
   for k in range(nr):
     skip = f'L_l_{k}'
@@ -856,7 +901,7 @@ def gen(rb, wide=True):
     a('s_waitcnt lgkmcnt(0)')
     combine(k, LN_BUF[0])
     a.label(skip)
-  a(f's_branch {L("L_next")}')
+  next_op()
 
   # ---- diagonal op: groups of phase factors -------------------------------------------
   # SGPRs here: s[48:49] tables base, s[52:67] group header (lane_mask reg_mask
@@ -1033,11 +1078,13 @@ def gen(rb, wide=True):
   a(f's_cbranch_scc1 {L("L_next")}')
   for k in range(0, nr, 4):
     cmul_slots(a, list(range(k, min(k + 4, nr))), cr, ci)
-  a(f's_branch {L("L_next")}')
+  next_op()
 
   # ---- store the tile -------------------------------------------------------------------
   a.label('L_done')
   tile_io(store=True)
+  prof_rec()
+  prof_rec(wait_stores=True, real_at=127)
   a('s_nop 0')
 
   # s_branch / s_cbranch reach +-32 Ki dwords (128 KiB).  The complex64 RB=6 island is ~180 KiB of code:
@@ -1046,16 +1093,17 @@ def gen(rb, wide=True):
   if len(a.lines) > 20000:
     lab = lambda nm: a.lines.index(f'{nm}_%=:')
     i_op, i_sec, i_done = lab('L_op'), lab('L_reg0'), lab('L_done')
-    tops = [lab(nm) for nm in ('L_real', 'L_rrc0', 'L_lane_real', 'L_bf', 'L_bfl', 'L_lswap', 'L_wswap', 'L_dpp', 'L_lrd',
+    tops = [lab(nm) for nm in ('L_real', 'L_rrc0', 'L_lane_real', 'L_bf', 'L_bfl_e', 'L_lswap', 'L_wswap', 'L_dpp', 'L_lrd',
                                'L_lane', 'L_diag')]
     mid = (i_sec + i_done) // 2
     cut = min((i for i in tops if i >= mid), default=tops[-1])
-    assert a.lines[cut - 1].startswith('s_branch '), 'the section before the cut must not fall through'
-    assert a.lines[i_sec - 1].startswith('s_branch ') and i_op < i_sec < cut < i_done
+    ends = ('s_branch ', 's_setpc_b64 ')
+    assert a.lines[cut - 1].startswith(ends), 'the section before the cut must not fall through'
+    assert a.lines[i_sec - 1].startswith(ends) and i_op < i_sec < cut < i_done
     a.lines = ([f's_branch {L("L_entry")}'] + a.lines[i_sec:cut] + [f'{L("L_entry")}:'] + a.lines[:i_sec] +
                a.lines[cut:])
   clob = ([f'v{i}' for i in range(TEMP_LO, T0 + 2 * W() * nr)] + [f's{i}' for i in range(16, 28)] + [f's{i}' for i in range(36, 100)] +
-          ['vcc', 'scc', 'memory'])
+          (['s28', 's29', 's30', 's31', 's101'] if prof else []) + ['vcc', 'scc', 'memory'])
   names = {'0': 'blo', '1': 'bhi', '2': 'prm', '3': 'tidx', '4': 'voff', '5': 'lane', '6': 'itlo', '7': 'ithi',
            '8': 'wave', '9': 'lds'}
   lines = [re.sub(r'%(\d)(?!\d)', lambda m: '%[' + names[m.group(1)] + ']', ln) for ln in a.lines]
@@ -1066,12 +1114,18 @@ def gen(rb, wide=True):
           '    : [tidx] "+s"(tile_idx), [itlo] "+v"(it_lo), [ithi] "+v"(it_hi)\n'
           '    : [blo] "s"(base_lo), [bhi] "s"(base_hi), [prm] "s"(prm), [voff] "v"(voff), [lane] "v"(lane_u),\n'
           '      [wave] "s"(wave_s), [lds] "s"(lds_base), [ltab] "s"(lds_ltab),\n'
-          '      [sblo] "s"(sbase_lo), [sbhi] "s"(sbase_hi), [svoff] "v"(svoff)\n'
+          '      [sblo] "s"(sbase_lo), [sbhi] "s"(sbase_hi), [svoff] "v"(svoff)' + (', [prow] "s"(prof_row)' if prof else '') + '\n'
           f'    : {cl});\n')
 
 
 def main():
   out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'qcc_amd', 'csrc')
+  if PROF:
+    path = os.path.join(out, 'sweep_island_prof_rb5.inc')
+    with open(path, 'w') as f:
+      f.write(gen(5, True, prof=True))
+    print('wrote', path)
+    return 0
   for wide in (True, False):
     for rb in (2, 3, 4, 5) + (() if wide else (6,)):     # complex64: 64 amplitudes per lane fit the same 128 VGPRs
       path = os.path.join(out, f'sweep_island_rb{rb}.inc' if wide else f'sweep_island_f32_rb{rb}.inc')
