@@ -272,6 +272,9 @@ def gen(rb, wide=True, prof=False):
   a(f's_branch {L("L_op")}')
   for t in targets:
     a(f's_branch {L(t)}')
+  gmasks = [1 << b for b in range(rb)] + [(1 << b0) | (1 << b1) for b0 in range(rb) for b1 in range(b0 + 1, rb)]
+  for t in ['L_gm0'] + [f'L_gm{m}' for m in gmasks] + ['L_gmx']:   # apply handlers of DIAG groups (see L_diag)
+    a(f's_branch {L(t)}')
   a.label('L_op')
   op_head()
   a.label('L_dense')
@@ -923,6 +926,67 @@ def gen(rb, wide=True, prof=False):
       a(f'v_cvt_f32_f64 v39, {sim}')
       cmul_vv(a, ur, ui, 'v38', 'v39', dt)
 
+  # Control flow (a taken branch costs a wave ~50 cycles, see the op dispatch above): the host marks a
+  # group GENERAL (flags bit 2) when it has a lane table, chunk tables or outside terms; every other
+  # group -- f = phi0 on the lanes that satisfy lane_mask -- runs straight through.  The apply code is
+  # reached through the handler table (entries NHID.., number in flags bits 8..15: 0 = no register mask,
+  # then the 1- and 2-bit masks, last = any other mask), and every apply handler ends with its own copy of
+  # the group head: two jumps per group instead of eight.
+  masks = [1 << b for b in range(rb)] + [(1 << b0) | (1 << b1) for b0 in range(rb) for b1 in range(b0 + 1, rb)]
+  gtargets = ['L_gm0'] + [f'L_gm{m}' for m in masks] + ['L_gmx']
+  nuniq = [0]
+
+  def f_from_u():                              # f = lane_ok ? u : 1
+    a(f'v_and_b32 v{V_A}, s52, %5')
+    a(f'v_cmp_eq_u32 vcc, s52, v{V_A}')
+    if DT.wide:
+      a(f'v_mov_b32 v{V_B}, 0x3ff00000')
+      a(f'v_cndmask_b32 v{D_F[0]}, 0, v{D_U[0]}, vcc')
+      a(f'v_cndmask_b32 v{D_F[0] + 1}, v{V_B}, v{D_U[0] + 1}, vcc')
+      a(f'v_cndmask_b32 v{D_F[1]}, 0, v{D_U[1]}, vcc')
+      a(f'v_cndmask_b32 v{D_F[1] + 1}, 0, v{D_U[1] + 1}, vcc')
+    else:
+      a(f'v_cndmask_b32 v{D_F[0]}, 1.0, v{D_U[0]}, vcc')
+      a(f'v_cndmask_b32 v{D_F[1]}, 0, v{D_U[1]}, vcc')
+
+  def u_from_header():
+    if DT.wide:
+      a(f'v_mov_b32 v{D_U[0]}, s56')
+      a(f'v_mov_b32 v{D_U[0] + 1}, s57')         # u = phi0 (wave-uniform value held in VGPRs)
+      a(f'v_mov_b32 v{D_U[1]}, s58')
+      a(f'v_mov_b32 v{D_U[1] + 1}, s59')
+    else:
+      a(f'v_cvt_f32_f64 v{D_U[0]}, s[56:57]')
+      a(f'v_cvt_f32_f64 v{D_U[1]}, s[58:59]')
+
+  def grp_dispatch():
+    # the header is consumed: remember reg_mask, advance, prefetch the NEXT group's header into the same
+    # SGPRs (one past the last group is readable memory: oterms / tables follow) and jump to the apply code
+    a('s_mov_b32 s72, s53')
+    a('s_bfe_u32 s74, s60, 0x80008')
+    a('s_add_u32 s92, s92, 64')
+    a('s_addc_u32 s93, s93, 0')
+    a('s_add_u32 s96, s96, 1')
+    a('s_load_dwordx16 s[52:67], s[92:93], 0x0')
+    a('s_lshl_b32 s74, s74, 2')
+    a(f's_add_u32 s74, s74, {4 * NHID}')
+    a('s_add_u32 s98, s24, s74')
+    a('s_addc_u32 s99, s25, 0')
+    a('s_setpc_b64 s[98:99]')
+
+  def grp_body():
+    a('s_waitcnt lgkmcnt(0)')
+    a('s_bitcmp1_b32 s60, 2')                    # DG_GENERAL
+    a(f's_cbranch_scc1 {L("L_grp_gen")}')
+    u_from_header()
+    f_from_u()
+    grp_dispatch()
+
+  def grp_tail():
+    a('s_cmp_lt_u32 s96, s47')
+    a(f's_cbranch_scc0 {L("L_diag_end")}')
+    grp_body()
+
   a.label('L_diag')
   if DT.wide:
     a(f'v_mov_b32 v{D_C[0]}, 0')
@@ -942,16 +1006,11 @@ def gen(rb, wide=True, prof=False):
   a('s_addc_u32 s93, s39, 0')
   a('s_mov_b32 s96, 0')
   a('s_load_dwordx16 s[52:67], s[92:93], 0x0')
-  a.label('L_grp')
-  a('s_waitcnt lgkmcnt(0)')
-  if DT.wide:
-    a(f'v_mov_b32 v{D_U[0]}, s56')
-    a(f'v_mov_b32 v{D_U[0] + 1}, s57')         # u = phi0 (wave-uniform value held in VGPRs)
-    a(f'v_mov_b32 v{D_U[1]}, s58')
-    a(f'v_mov_b32 v{D_U[1] + 1}, s59')
-  else:
-    a(f'v_cvt_f32_f64 v{D_U[0]}, s[56:57]')
-    a(f'v_cvt_f32_f64 v{D_U[1]}, s[58:59]')
+  grp_body()
+
+  # general group: lane table, chunk tables, outside terms
+  a.label('L_grp_gen')
+  u_from_header()
   a('s_bitcmp1_b32 s60, 0')                    # LTAB: start the 1-KiB lane-table load early
   a(f's_cbranch_scc0 {L("L_g1")}')
   a('s_lshl_b32 s74, s61, 4')
@@ -1021,40 +1080,23 @@ def gen(rb, wide=True, prof=False):
   a(MUL() + f' {fi}, {lt_r}, {ui}')
   a(FMA() + f' {fr}, -{lt_i}, {ui}, {fr}')
   a(FMA() + f' {fi}, {lt_i}, {ur}, {fi}')
-  a(f's_branch {L("L_g4")}')
-  a.label('L_g3')                              # f = lane_ok ? u : 1
-  a(f'v_and_b32 v{V_A}, s52, %5')
-  a(f'v_cmp_eq_u32 vcc, s52, v{V_A}')
-  if DT.wide:
-    a(f'v_mov_b32 v{V_B}, 0x3ff00000')
-    a(f'v_cndmask_b32 v{D_F[0]}, 0, v{D_U[0]}, vcc')
-    a(f'v_cndmask_b32 v{D_F[0] + 1}, v{V_B}, v{D_U[0] + 1}, vcc')
-    a(f'v_cndmask_b32 v{D_F[1]}, 0, v{D_U[1]}, vcc')
-    a(f'v_cndmask_b32 v{D_F[1] + 1}, 0, v{D_U[1] + 1}, vcc')
-  else:
-    a(f'v_cndmask_b32 v{D_F[0]}, 1.0, v{D_U[0]}, vcc')
-    a(f'v_cndmask_b32 v{D_F[1]}, 0, v{D_U[1]}, vcc')
-  a.label('L_g4')
-  # the header is consumed: remember reg_mask, advance, and prefetch the NEXT group's
-  # header into the same SGPRs while the VALU applies this group's factor
-  a('s_mov_b32 s72, s53')
-  a('s_add_u32 s92, s92, 64')
-  a('s_addc_u32 s93, s93, 0')
-  a('s_add_u32 s96, s96, 1')
-  a('s_cmp_lt_u32 s96, s47')
-  a(f's_cbranch_scc0 {L("L_g5")}')
-  a('s_load_dwordx16 s[52:67], s[92:93], 0x0')
-  a.label('L_g5')
-  a('s_cmp_eq_u32 s72, 0')
-  a(f's_cbranch_scc0 {L("L_grp_r")}')
+  grp_dispatch()
+  a.label('L_g3')
+  f_from_u()
+  grp_dispatch()
+
+  # apply handlers
+  a.label('L_gm0')
   cmul_vv(a, cr, ci, fr, fi, dt)               # reg_mask == 0: c *= f
   a('s_mov_b32 s75, 1')
-  a(f's_branch {L("L_grp_n")}')
-  a.label('L_grp_r')
-  masks = [1 << b for b in range(rb)] + [(1 << b0) | (1 << b1) for b0 in range(rb) for b1 in range(b0 + 1, rb)]
+  grp_tail()
   for m in masks:                              # 1- and 2-bit register masks: straight-line code
-    a(f's_cmp_eq_u32 s72, {m}')
-    a(f's_cbranch_scc1 {L(f"L_gm{m}")}')
+    a.label(f'L_gm{m}')
+    slots = [k for k in range(nr) if (k & m) == m]
+    for i in range(0, len(slots), 4):
+      cmul_slots(a, slots[i:i + 4], fr, fi)
+    grp_tail()
+  a.label('L_gmx')
   for k in range(nr):                          # any other register mask
     skip = f'L_g_{k}'
     a(f's_andn2_b32 s74, s72, {k}')
@@ -1062,16 +1104,9 @@ def gen(rb, wide=True, prof=False):
     a(f's_cbranch_scc0 {L(skip)}')
     cmul_slots(a, [k], fr, fi)
     a.label(skip)
-  a(f's_branch {L("L_grp_n")}')
-  for m in masks:
-    a.label(f'L_gm{m}')
-    slots = [k for k in range(nr) if (k & m) == m]
-    for i in range(0, len(slots), 4):
-      cmul_slots(a, slots[i:i + 4], fr, fi)
-    a(f's_branch {L("L_grp_n")}')
-  a.label('L_grp_n')
-  a('s_cmp_lt_u32 s96, s47')
-  a(f's_cbranch_scc1 {L("L_grp")}')
+  grp_tail()
+
+  a.label('L_diag_end')
   a('s_cmp_eq_u32 s75, 0')
   a(f's_cbranch_scc1 {L("L_next")}')
   a('s_bitcmp1_b32 s51, 0')                    # DEFER_C: the next (lane) op folds c into its matrix
