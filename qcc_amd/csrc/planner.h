@@ -900,6 +900,10 @@ class Planner {
       op.kind = OP_LSWAP;
       op.tb = (uint32_t)li;
       op.cm_reg = (uint32_t)r;
+      // the kernel moves the thread's own bit from the lane's index position to the register's (its thread
+      // index keeps describing the amplitudes it holds: lane / outside controls and OP_WSWAP rely on it)
+      op.n_groups = (uint32_t)geom.lanehi[li - geom.lane_low];
+      op.cm_thread = (1ull << geom.lanehi[li - geom.lane_low]) | (1ull << geom.regpos[r]);
       sp->ops.push_back(op);
       std::swap(geom.lanehi[li - geom.lane_low], geom.regpos[r]);
     };
@@ -933,9 +937,26 @@ class Planner {
         size_t next = taken.size() + 1;
         for (size_t j = gi_now + 1; j < taken.size(); ++j)
           if (!plan_diag(taken[j]->g, taken[j]->tgt) && taken[j]->tgt == geom.regpos[r]) { next = j; break; }
-        if (next > best_next) { best_next = next; best = r; }
+        // ties: a register no exchange has touched yet (its exchange can then be undone, or left, on its own)
+        bool used = false, best_used = false;
+        for (const Swap &w : swaps) { used |= w.r == r; best_used |= w.r == best; }
+        if (next > best_next || (next == best_next && best_used && !used)) { best_next = next; best = r; }
       }
       return best;
+    };
+    // Undo the lane exchanges only (in-place store with the wave bits left exchanged): possible when no
+    // later wave exchange went through the same register bit; false = the caller restores everything.
+    auto undo_lane_swaps = [&]() {
+      for (size_t i = 0; i < swaps.size(); ++i)
+        if (!swaps[i].wave)
+          for (size_t j = i + 1; j < swaps.size(); ++j)
+            if (swaps[j].wave && swaps[j].r == swaps[i].r) return false;
+      for (size_t i = swaps.size(); i-- > 0;)
+        if (!swaps[i].wave) {
+          lswap(swaps[i].idx, swaps[i].r);
+          swaps.erase(swaps.begin() + (long)i);
+        }
+      return true;
     };
     std::vector<PTerm> pending;
     auto add_pending = [&](uint64_t mask, double re, double im) {
@@ -954,13 +975,7 @@ class Planner {
         // a target that lives in the wave id comes into a register bit first: the phases
         // waiting for this gate are then in-tile factors instead of one group per partner bit
         gi_now = gi;
-        int wi = wave_index(geom, r->tgt);
-        if (wi >= 0 && lane_swapped()) {
-          // (the index-bit bookkeeping of OP_WSWAP assumes the register bits are register
-          // bits of the ORIGINAL lane map: undo lane exchanges first)
-          restore_layout();
-          wi = wave_index(geom, r->tgt);
-        }
+        const int wi = wave_index(geom, r->tgt);
         if (wi >= 0) {
           const int vr = victim_reg();
           wswap(wi, vr);
@@ -975,19 +990,6 @@ class Planner {
         uint32_t nlane = 0, nreg = 0; uint64_t noutside = 0, nlane_phys = 0;   // zero-controls
         split_mask(geom, r->ctl_mask, &lane, &lane_phys, &reg, &outside);
         if (r->neg_mask) split_mask(geom, r->neg_mask, &nlane, &nlane_phys, &nreg, &noutside, false);
-        if ((lane | nlane) && lane_swapped()) {
-          // lane-bit controls are tested against the thread's ORIGINAL lane -> index-bit map
-          restore_layout();
-          const int wj = wave_index(geom, r->tgt);
-          if (wj >= 0) {
-            const int vr = victim_reg();
-            wswap(wj, vr);
-            swaps.push_back(Swap{1, wj, vr});
-          }
-          n_ops_after_flush = 0;
-          split_mask(geom, r->ctl_mask, &lane, &lane_phys, &reg, &outside);
-          if (r->neg_mask) split_mask(geom, r->neg_mask, &nlane, &nlane_phys, &nreg, &noutside, false);
-        }
         // thread controls: (index & cm_thread) == cm_thread & ~zero-controls; the zero-control
         // mask of a dense op travels in the two header words a DIAG op uses for its groups
         const uint64_t nthread = noutside | nlane_phys;
@@ -1084,7 +1086,7 @@ class Planner {
     if (want_relayout(*sp)) {
       sp->relayout = true;      // (dest_pos: plan() -> finish_relayout, once the next sweep's targets are known)
     } else if (store_swapped_ && sp->contiguous()) {
-      while (!swaps.empty() && !swaps.back().wave) { lswap(swaps.back().idx, swaps.back().r); swaps.pop_back(); }
+      if (!undo_lane_swaps()) restore_layout();
     } else {
       restore_layout();
     }

@@ -117,6 +117,8 @@ def run_plan(psi, sweeps, nloc, shard=0):
       kind, tb, flags = int(op['kind']), int(op['tb']), int(op['flags'])
       if kind == OP_LSWAP:
         r = int(op['cm_reg'])
+        # kernel bookkeeping operands: the lane bit's index position, and both positions as a mask
+        assert int(op['n_groups']) == lanepos[tb] and int(op['cm_thread']) == (1 << lanepos[tb]) | (1 << regpos[r])
         lanepos[tb], regpos[r] = regpos[r], lanepos[tb]
         continue
       if kind == OP_WSWAP:

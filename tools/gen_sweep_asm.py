@@ -633,6 +633,17 @@ def gen(rb, wide=True, prof=False):
           continue
         for d in range(2 * W()):
           a(f'{ins} v{T(k) + d}, v{T(k | (1 << r)) + d}')
+      # the thread's own bit moves with the exchange: header n_groups = the lane bit's index position,
+      # cm_thread = that bit | the register bit's position (which holds 0 in a thread index)
+      a('s_lshl_b64 s[72:73], 1, s47')
+      a(f'v_and_b32 v{V_A}, s72, %6')
+      a(f'v_and_b32 v{V_B}, s73, %7')
+      a(f'v_or_b32 v{V_A}, v{V_A}, v{V_B}')
+      a(f'v_cmp_ne_u32 vcc, 0, v{V_A}')
+      a(f'v_xor_b32 v{V_A}, s48, %6')
+      a(f'v_xor_b32 v{V_B}, s49, %7')
+      a(f'v_cndmask_b32 %6, %6, v{V_A}, vcc')
+      a(f'v_cndmask_b32 %7, %7, v{V_B}, vcc')
       next_op()
 
   # ---- OP_WSWAP: wave bit tb <-> register bit r (header field cm_reg) --------------------
