@@ -108,6 +108,19 @@ struct OTerm {
 //   lane table: 64 entries, product of all merged pure-lane factors.
 constexpr uint32_t DG_LTAB = 1u;
 constexpr uint32_t DG_LTAB_LDS = 2u;   // set at launch: this sweep's lane tables were copied into LDS
+// (bit 2 and bits 8..15 are set at launch too: kernels_sweep.hip.h group_handler_bits)
+// DG_BITFAC: reg_mask is ONE register bit j and tab_off[3] points at four more factors w_0..w_3, one per
+// register bit of bitfac_others(rb, j): a slot with bit j set is multiplied by f times the w_k of its set bits.
+// The kernel walks the 2^4 subsets as a tree (one complex product per slot to derive the factor, one to
+// apply it), so the controlled phases between one target and the other register bits -- a QFT's ladder --
+// cost ONE group instead of one per partner bit.
+constexpr uint32_t DG_BITFAC = 8u;
+constexpr int kBitFacs = 4;
+inline int bitfac_others(int rb, int j, int out[kBitFacs]) {   // the first four register bits other than j
+  int n = 0;
+  for (int b = 0; b < rb && n < kBitFacs; ++b) if (b != j) out[n++] = b;
+  return n;
+}
 struct DGroup {
   uint32_t lane_mask, reg_mask;
   uint32_t oterm_off, n_oterms;
@@ -327,6 +340,7 @@ class Planner {
   bool lanes_by_count_ = env_flag("QH_LANES_BY_COUNT", true);
   bool lanes_high_ = env_flag("QH_LANES_HIGH", true);
   int min_table_terms_ = env_int("QH_MIN_TABLE_TERMS", 2);
+  bool bitfac_ = env_flag("QH_BITFAC", true);            // DG_BITFAC groups (fuse_bit_factors)
   int lane_valu_ = env_int("QH_LANE_VALU", 1);          // 0 never, 1 by cost model (choose_lane_paths), 2 always (tests)
   bool defer_diag_ = env_flag("QH_DEFER_DIAG", true);   // see build_sweep
   bool lookahead_ = env_flag("QH_RELAYOUT_AHEAD", true); // see finish_relayout
@@ -1096,8 +1110,10 @@ class Planner {
     // lane tables go to the front of `tables` (one contiguous block: the kernel copies it to LDS)
     const uint32_t nlt = (uint32_t)(sp->ltabs.size() / 2);
     if (nlt) {
-      for (auto &g : sp->groups)
+      for (auto &g : sp->groups) {
         for (uint32_t t = 0; t < g.ntab; ++t) g.tab_off[t] += nlt;
+        if (g.flags & DG_BITFAC) g.tab_off[3] += nlt;
+      }
       sp->tables.insert(sp->tables.begin(), sp->ltabs.begin(), sp->ltabs.end());
       sp->ltabs.clear();
     }
@@ -1254,8 +1270,65 @@ class Planner {
       attach_outside(g, pg);
       sp->groups.push_back(g);
     }
+    fuse_bit_factors(sp, op.group_off, geom.rb);
     op.n_groups = (uint32_t)(sp->groups.size() - op.group_off);
     sp->ops.push_back(op);
+  }
+
+  // Scalar groups on two register bits {i, j} join the group on {j} as bit factors (DG_BITFAC).
+  void fuse_bit_factors(SweepPlan *sp, uint32_t first, int rb) const {
+    if (!bitfac_) return;
+    auto scalar2 = [](const DGroup &g) {
+      return g.lane_mask == 0 && g.flags == 0 && g.ntab == 0 && g.n_oterms == 0 && popc(g.reg_mask) == 2;
+    };
+    int best_j = -1, best_n = 0;
+    for (int j = 0; j < rb; ++j) {
+      int others[kBitFacs];
+      const int no = bitfac_others(rb, j, others);
+      int n = 0;
+      for (size_t k = first; k < sp->groups.size(); ++k) {
+        const DGroup &g = sp->groups[k];
+        if (!scalar2(g) || !(g.reg_mask >> j & 1)) continue;
+        const int i = __builtin_ctz(g.reg_mask & ~(1u << j));
+        for (int t = 0; t < no; ++t) n += others[t] == i;
+      }
+      if (n > best_n) { best_n = n; best_j = j; }
+    }
+    if (best_j < 0) return;
+    int base = -1;
+    for (size_t k = first; k < sp->groups.size(); ++k)
+      if (sp->groups[k].reg_mask == (1u << best_j) && sp->groups[k].ntab <= 3) { base = (int)k; break; }
+    if (best_n < (base >= 0 ? 2 : 3)) return;
+    int others[kBitFacs];
+    const int no = bitfac_others(rb, best_j, others);
+    double w[2 * kBitFacs] = {1, 0, 1, 0, 1, 0, 1, 0};
+    std::vector<DGroup> kept;
+    const int base_abs = base;
+    for (size_t k = first; k < sp->groups.size(); ++k) {
+      const DGroup &g = sp->groups[k];
+      int slot = -1;
+      if (scalar2(g) && (g.reg_mask >> best_j & 1)) {
+        const int i = __builtin_ctz(g.reg_mask & ~(1u << best_j));
+        for (int t = 0; t < no; ++t) if (others[t] == i) slot = t;
+      }
+      if (slot < 0) { kept.push_back(g); continue; }
+      cmul_acc(&w[2 * slot], &w[2 * slot + 1], g.re, g.im);
+      if ((int)k < base_abs) base--;           // (k == base_abs cannot happen: the base has a 1-bit mask)
+    }
+    if (base < 0) {
+      DGroup g{};
+      g.reg_mask = 1u << best_j;
+      g.re = 1; g.im = 0;
+      kept.push_back(g);
+      base = (int)kept.size() - 1;
+    } else {
+      base -= (int)first;
+    }
+    kept[base].flags |= DG_BITFAC;
+    kept[base].tab_off[3] = (uint32_t)(sp->tables.size() / 2);
+    for (double x : w) sp->tables.push_back(x);
+    sp->groups.resize(first);
+    for (const DGroup &g : kept) sp->groups.push_back(g);
   }
 };
 

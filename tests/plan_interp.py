@@ -15,6 +15,7 @@ from qcc_amd import native
 OP_DENSE_REG, OP_DENSE_LANE, OP_DIAG, OP_LSWAP, OP_WSWAP = 0, 1, 2, 3, 4
 OPF_REAL, OPF_BFLY, OPF_LANE_DPP, OPF_SWAP_RI = 4, 8, 128, 256
 DG_LTAB = 1
+DG_BITFAC = 8
 
 OP_DT = np.dtype([('kind', '<u4'), ('tb', '<u4'), ('cm_reg', '<u4'), ('n_groups', '<u4'), ('cm_thread', '<u8'),
                   ('group_off', '<u4'), ('flags', '<u4'), ('g', '<f8', (8,))])
@@ -143,6 +144,14 @@ def run_plan(psi, sweeps, nloc, shard=0):
             lm = np.uint64(g['lane_mask'])
             f = np.where((lane & lm) == lm, u, 1.0)
           rm = np.uint64(g['reg_mask'])
+          if int(g['flags']) & DG_BITFAC:
+            # one register bit j; four more factors, one per register bit of the first four others
+            j = int(g['reg_mask']).bit_length() - 1
+            assert int(g['reg_mask']) == 1 << j
+            others = [b for b in range(rb) if b != j][:4]
+            w = tab[int(g['tab_off'][3]): int(g['tab_off'][3]) + 4]
+            for t, b in enumerate(others):
+              f = np.where((slot >> np.uint64(b)) & np.uint64(1) == 1, f * w[t], f)
           factor = np.where((slot & rm) == rm, factor * f, factor)
         psi[in_sweep] = (psi * factor.astype(psi.dtype))[in_sweep]
         continue

@@ -273,7 +273,7 @@ def gen(rb, wide=True, prof=False):
   for t in targets:
     a(f's_branch {L(t)}')
   gmasks = [1 << b for b in range(rb)] + [(1 << b0) | (1 << b1) for b0 in range(rb) for b1 in range(b0 + 1, rb)]
-  for t in ['L_gm0'] + [f'L_gm{m}' for m in gmasks] + ['L_gmx']:   # apply handlers of DIAG groups (see L_diag)
+  for t in ['L_gm0'] + [f'L_gm{m}' for m in gmasks] + ['L_gmx'] + [f'L_gbf{j}' for j in range(rb)]:   # apply handlers of DIAG groups (see L_diag)
     a(f's_branch {L(t)}')
   a.label('L_op')
   op_head()
@@ -974,6 +974,7 @@ def gen(rb, wide=True, prof=False):
     # the header is consumed: remember reg_mask, advance, prefetch the NEXT group's header into the same
     # SGPRs (one past the last group is readable memory: oterms / tables follow) and jump to the apply code
     a('s_mov_b32 s72, s53')
+    a('s_mov_b32 s73, s67')                      # tab_off[3]: the bit factors of a DG_BITFAC group
     a('s_bfe_u32 s74, s60, 0x80008')
     a('s_add_u32 s92, s92, 64')
     a('s_addc_u32 s93, s93, 0')
@@ -1116,6 +1117,76 @@ def gen(rb, wide=True, prof=False):
     cmul_slots(a, [k], fr, fi)
     a.label(skip)
   grp_tail()
+
+  # DG_BITFAC (planner.h): slots with register bit j set take f x the factors w_k of their other set bits;
+  # the subsets of those bits are walked as a tree, parent factor x w_k -> child factor (kept in VGPRs for
+  # the inner nodes: three levels), so every slot costs two complex products at most.
+  def bitfac(j):
+    others = [b for b in range(rb) if b != j][:4]
+    free = [b for b in range(rb) if b != j and b not in others]
+    a('s_lshl_b32 s73, s73, 4')
+    a('s_load_dwordx16 s[76:91], s[48:49], s73')
+    if DT.wide:
+      wv = [(f's[{76 + 4 * t}:{77 + 4 * t}]', f's[{78 + 4 * t}:{79 + 4 * t}]') for t in range(4)]
+      levels = [(V2(22), V2(24)), (V2(30), V2(32)), (V2(34), V2(36))]
+      temps = [V2(16), V2(38)]
+    else:
+      wv = [(f'v{23 + 4 * t}', f'v{25 + 4 * t}') for t in range(4)]      # v23 v25 | v27 v29 | v31 v33 | v35 v37
+      levels = [('v22', 'v24'), ('v30', 'v32'), ('v34', 'v36')]
+      temps = ['v16', 'v17', 'v38', 'v39']
+
+    def expand(slot):
+      out = [slot]
+      for b in free:
+        out += [x | (1 << b) for x in out]
+      return out
+
+    def cmul_by(slots, pr, pi):
+      for i in range(0, len(slots), len(temps)):
+        part = slots[i:i + len(temps)]
+        for t, k in zip(temps, part):
+          a(MUL() + f' {t}, {Y(k)}, {pi}')
+        for t, k in zip(temps, part):
+          a(MUL() + f' {Y(k)}, {Y(k)}, {pr}')
+        for t, k in zip(temps, part):
+          a(FMA() + f' {Y(k)}, {X(k)}, {pi}, {Y(k)}')
+        for t, k in zip(temps, part):
+          a(FMA() + f' {X(k)}, {X(k)}, {pr}, -{t}')
+
+    waited = [False]
+
+    def need_w():
+      if not waited[0]:
+        a('s_waitcnt lgkmcnt(0)')
+        if not DT.wide:
+          for t in range(4):
+            a(f'v_cvt_f32_f64 {wv[t][0]}, s[{76 + 4 * t}:{77 + 4 * t}]')
+            a(f'v_cvt_f32_f64 {wv[t][1]}, s[{78 + 4 * t}:{79 + 4 * t}]')
+        waited[0] = True
+
+    def visit(F, rem, slot, level):
+      last = rem[-1] if rem else None
+      mine = expand(slot)
+      leaf = expand(slot | (1 << others[last])) if rem else []
+      cmul_by(mine + leaf, F[0], F[1])
+      if rem:
+        need_w()
+        cmul_by(leaf, wv[last][0], wv[last][1])
+      for idx, t in enumerate(rem[:-1]):
+        need_w()
+        C = levels[level]
+        a(MUL() + f' {C[0]}, {F[0]}, {wv[t][0]}')
+        a(MUL() + f' {C[1]}, {F[0]}, {wv[t][1]}')
+        a(FMA() + f' {C[0]}, -{F[1]}, {wv[t][1]}, {C[0]}')
+        a(FMA() + f' {C[1]}, {F[1]}, {wv[t][0]}, {C[1]}')
+        visit(C, rem[idx + 1:], slot | (1 << others[t]), level + 1)
+
+    visit((fr, fi), list(range(len(others))), 1 << j, 0)
+
+  for j in range(rb):
+    a.label(f'L_gbf{j}')
+    bitfac(j)
+    grp_tail()
 
   a.label('L_diag_end')
   a('s_cmp_eq_u32 s75, 0')
