@@ -828,9 +828,9 @@ class Planner {
   // tools/probes/prof_island.sh): a bpermute butterfly keeps its wave for 3 200-7 700 cycles when the other
   // eleven waves of the CU queue at the same pipe, a DPP one for 1 300-3 000, swap + register butterfly for
   // 1 800-2 500.  So a sweep whose LDS pipe would be busy for more than QH_LDS_FLOOR cycles per tile
-  // (default 3 500: half of the HBM time of a tile) moves ALL its lane butterflies to the VALU; lighter
-  // sweeps (a QFT's second and third: three lane targets) are HBM-bound either way and keep the LDS path,
-  // which draws less power (30-qubit QFT first sweep 6.7 -> 6.35 ms, supremacy 47.9 -> 47.1, QFT-33 159 -> 153).
+  // (default 2 500: a third of the HBM time of a tile -- three lane butterflies and a wave exchange) moves
+  // ALL its lane butterflies to the VALU; lighter sweeps keep the LDS path (30-qubit QFT first sweep
+  // 6.7 -> 6.35 ms, its other two 6.05 -> 5.87; supremacy 47.9 -> 47.1; QFT-33 159 -> 153).
   LaneChoice choose_lane_paths(const SweepPlan &sp) const {
     const double kLds = 6.1 * (amp_bytes_ == 16 ? 128 : 64);
     const double dw = amp_bytes_ == 16 ? 1.0 : 0.5;
@@ -839,7 +839,7 @@ class Planner {
       if (o.kind == OP_WSWAP) lds += 256 * dw;      // 16 ds_write_b128 + 16 ds_read_b128, 8 cycles each
       else if (o.kind == OP_DENSE_LANE) lds += kLds;
     }
-    static const double floor_cycles = env_int("QH_LDS_FLOOR", 3500);
+    static const double floor_cycles = env_int("QH_LDS_FLOOR", 2500);
     LaneChoice ch;
     if (lds > floor_cycles) ch.dpp01 = ch.dpp23 = ch.lswap = ch.real01 = ch.real23 = 1 << 20;
     return ch;

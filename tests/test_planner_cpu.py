@@ -54,11 +54,11 @@ def test_qft30_is_three_sweeps_and_accounts_every_gate():
   # (split lanes) gather their tile and store it contiguously into the second buffer: the wave bit is
   # swapped into a register and the displaced bit once more, and nothing is swapped back
   assert [s['relayout'] for s in sw] == [0, 1, 1]
-  assert [s['lswap_ops'] for s in sw] == [7, 2, 2]
-  # sweep 1 has six lane targets: its LDS pipe would be the busiest unit, so its lane butterflies run on the VALU
-  # (DPP partner fetch for lane bits 0..3, v_permlane swaps for 4 and 5: three exchanges in, three back, one for
-  # the wave bit); sweeps 2 and 3 have three lane targets and keep ds_bpermute (planner.h choose_lane_paths)
-  assert [s['dpp_ops'] for s in sw] == [4, 0, 0]
+  # lane butterflies run on the VALU (planner.h choose_lane_paths): DPP partner fetch for lane bits 0..3,
+  # v_permlane swaps for 4 and 5.  Sweep 1 (six lane targets, in place): three exchanges in, three back, one for
+  # the wave bit; sweeps 2 and 3 (three lane targets, relayout: nothing is exchanged back)
+  assert [s['lswap_ops'] for s in sw] == [7, 4, 4]
+  assert [s['dpp_ops'] for s in sw] == [4, 1, 1]
   # minimal-touch bytes of BASELINE.md: 30 H x 2S + 435 CU1 x S/2 = 277.5 S
   assert sum(s['alg_bytes'] for s in sw) == int(277.5 * S)
   # lazy diagonal placement + tables: (almost) no per-gate loop terms left
