@@ -8,6 +8,7 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-ladder-base --no-cached-plan"
 timeout 600 python $R/bench.py > $O/bench_default.json 2> $O/bench_default.err
+timeout 600 python $R/bench.py --steps 20 --warmup 5 > $O/bench_driver_style.json 2> $O/bench_driver_style.err
 QH_RELAYOUT=0 timeout 300 python $R/bench.py --no-cpu-baseline --no-ladder-base --no-cached-plan > $O/bench_inplace.json 2> $O/bench_inplace.err
 timeout 300 python $R/bench.py --fusion 0 --steps 2 --no-cpu-baseline > $O/bench_unfused.json 2> $O/bench_unfused.err
 stats() {  # stats <tag> <command...>: rocprofv3 --kernel-trace --stats -> $O/<tag>_kernel_stats.csv
@@ -70,3 +71,9 @@ done
 timeout 900 python $R/tools/bench_configs.py > $O/bench_configs.json 2>&1
 rm -f $O/*_stats.log $O/pmc_*.log
 ls -la $O; head -c 2500 $O/bench_default.json; echo; cat $O/translation_counters_qft30.txt | head -60
+# per-op timeline of a wave inside the sweep kernel (measurement build of the island, tools/probes/prof_island.sh)
+if [ -f $R/tools/probes/libqcc_hip_prof.so ]; then
+  for w in qft30 sup30; do
+    bash $R/tools/probes/prof_island.sh run $w /tmp/prof_$w.txt > $O/op_timeline_$w.txt 2>&1
+  done
+fi
