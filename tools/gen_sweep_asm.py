@@ -121,9 +121,29 @@ D_TMP = [30, 32, 34, 36]   # cmul temporaries (4 slots interleaved)
 D_LTAB = 34                # lane-table entry lands in v[34:37] (free until the apply phase)
 
 
+def vpair(r):
+  """'v26' -> 'v[26:27]'"""
+  n = int(r[1:])
+  return f'v[{n}:{n + 1}]'
+
+
+def pk_cmul(a, dst, src, f, tmp):
+  """complex64, packed: dst = src * f (register pairs (re, im); dst may be src; tmp another pair)."""
+  a(f'v_pk_mul_f32 {tmp}, {src}, {f} op_sel_hi:[1,0]')                                    # (x fr, y fr)
+  a(f'v_pk_fma_f32 {dst}, {src}, {f}, {tmp} op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]')   # (x fr - y fi, y fr + x fi)
+
+
 def cmul_slots(a, slots, fr, fi):
   """slot *= (fr,fi) for 1..4 slots, interleaved to hide the FP64 latency."""
   assert len(slots) <= 4
+  if not DT.wide and fr[0] == 'v' and fi == f'v{int(fr[1:]) + 1}':
+    f = vpair(fr)
+    tm = [f'v[{t}:{t + 1}]' for t in D_TMP]
+    for t, k in zip(tm, slots):
+      a(f'v_pk_mul_f32 {t}, v[{T(k)}:{T(k) + 1}], {f} op_sel_hi:[1,0]')
+    for t, k in zip(tm, slots):
+      a(f'v_pk_fma_f32 v[{T(k)}:{T(k) + 1}], v[{T(k)}:{T(k) + 1}], {f}, {t} op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]')
+    return
   tm = [V2(t) for t in D_TMP]
   # t = y*fi ; y = y*fr ; y += x*fi ; x = x*fr - t   (4 FP64 ops, result in place)
   for t, k in zip(tm, slots):
@@ -145,7 +165,11 @@ def cmul_vv(a, xr, xi, fr, fi, tmp):
 
 
 def gen(rb, wide=True, prof=False):
+  global D_C, D_U, D_F
   DT.wide = wide
+  # (re, im) of a temporary complex number sit in ADJACENT registers: complex64 multiplies by them with
+  # packed FP32 instructions (v_pk_mul_f32 / v_pk_fma_f32 take 64-bit register pairs)
+  D_C, D_U, D_F = (18, 18 + W()), (22, 22 + W()), (26, 26 + W())
   nr = 1 << rb
   a = Asm()
   batch = min(8, nr)
@@ -515,6 +539,28 @@ def gen(rb, wide=True, prof=False):
       for h in range(nr // 2):
         k0 = ((h >> b) << (b + 1)) | (h & ((1 << b) - 1))
         pairs.append((k0, k0 | (1 << b)))
+      if not DT.wide:
+        # complex64: one packed add and one packed fma per pair ((re, im) of a slot = one 64-bit register pair);
+        # K = (2, 2), signs and the re/im exchange of the v gates by neg_* / op_sel
+        a('v_mov_b32 v16, 2.0')
+        a('v_mov_b32 v17, 2.0')
+        P = lambda k: f'v[{T(k)}:{T(k) + 1}]'
+        first = {0: '', 1: ' neg_lo:[0,1] neg_hi:[0,1]', 2: '',
+                 3: ' op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]',       # a' = (ar + bi, ai - br)
+                 4: ' op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]'}[v]    # a' = (ar - bi, ai + br)
+        second = {0: ' neg_lo:[0,1,0] neg_hi:[0,1,0]',                    # b' = a' - 2b
+                  1: '',                                                  # b' = a' + 2b
+                  2: ' neg_lo:[0,0,1] neg_hi:[0,0,1]',                    # b' = 2b - a'
+                  3: ' op_sel:[0,0,1] op_sel_hi:[1,1,0] neg_hi:[0,0,1]',  # b' = (2br + ai', 2bi - ar')
+                  4: ' op_sel:[0,0,1] op_sel_hi:[1,1,0] neg_lo:[0,0,1]'}[v]   # b' = (2br - ai', 2bi + ar')
+        for i in range(0, len(pairs), 8):
+          grp = pairs[i:i + 8]
+          for k0, k1 in grp:
+            a(f'v_pk_add_f32 {P(k0)}, {P(k0)}, {P(k1)}{first}')
+          for k0, k1 in grp:
+            a(f'v_pk_fma_f32 {P(k1)}, {P(k1)}, v[16:17], {P(k0)}{second}')
+        next_op()
+        continue
       for i in range(0, len(pairs), 4):           # four pairs interleaved: 8 independent chains
         grp = pairs[i:i + 4]
         if v == 0:      # a' = a + b ; b' = a - b = a' - 2b
@@ -712,7 +758,7 @@ def gen(rb, wide=True, prof=False):
   a('s_lshl_b32 s75, 1, s45')
   a(f'v_and_b32 v{LN_TMP}, s75, %5')
   a(f'v_cmp_ne_u32 vcc, 0, v{LN_TMP}')
-  BRE, BIM, Q, TQ = 18, 18 + 2 * W(), 24, 28
+  BRE, BIM, Q, TQ = 18, (22 if DT.wide else 19), 24, 28     # complex64: (beta_re, beta_im) adjacent for the packed fma
   a('s_waitcnt lgkmcnt(0)')
   if DT.wide:
     for v, (lo, hi) in ((BRE, (52, 54)), (BIM, (56, 58))):
@@ -756,8 +802,11 @@ def gen(rb, wide=True, prof=False):
           a('s_nop 1')
         for d in range(nd):
           a(f'v_mov_b32_dpp v{Q + d}, v{TQ + d} {steps[1]} row_mask:0xf bank_mask:0xf')
-      a(FMA() + f' {X(k)}, {bre}, {V2(Q)}, {X(k)}')
-      a(FMA() + f' {Y(k)}, {bim}, {V2(Q + W())}, {Y(k)}')
+      if DT.wide:
+        a(FMA() + f' {X(k)}, {bre}, {V2(Q)}, {X(k)}')
+        a(FMA() + f' {Y(k)}, {bim}, {V2(Q + W())}, {Y(k)}')
+      else:
+        a(f'v_pk_fma_f32 v[{T(k)}:{T(k) + 1}], v[{BRE}:{BRE + 1}], v[{Q}:{Q + 1}], v[{T(k)}:{T(k) + 1}]')
     next_op()
 
 
@@ -1131,9 +1180,10 @@ def gen(rb, wide=True, prof=False):
       levels = [(V2(22), V2(24)), (V2(30), V2(32)), (V2(34), V2(36))]
       temps = [V2(16), V2(38)]
     else:
-      wv = [(f'v{23 + 4 * t}', f'v{25 + 4 * t}') for t in range(4)]      # v23 v25 | v27 v29 | v31 v33 | v35 v37
-      levels = [('v22', 'v24'), ('v30', 'v32'), ('v34', 'v36')]
-      temps = ['v16', 'v17', 'v38', 'v39']
+      # complex64: factors as (re, im) register pairs, packed arithmetic.  v18 v19 = c, v26 v27 = f.
+      wv = [('v20', 'v21'), ('v22', 'v23'), ('v24', 'v25'), ('v28', 'v29')]
+      levels = [('v30', 'v31'), ('v32', 'v33'), ('v34', 'v35')]
+      temps = ['v[16:17]', 'v[36:37]', 'v[38:39]']
 
     def expand(slot):
       out = [slot]
@@ -1142,6 +1192,15 @@ def gen(rb, wide=True, prof=False):
       return out
 
     def cmul_by(slots, pr, pi):
+      if not DT.wide:
+        f = vpair(pr)
+        for i in range(0, len(slots), len(temps)):
+          part = slots[i:i + len(temps)]
+          for t, k in zip(temps, part):
+            a(f'v_pk_mul_f32 {t}, v[{T(k)}:{T(k) + 1}], {f} op_sel_hi:[1,0]')
+          for t, k in zip(temps, part):
+            a(f'v_pk_fma_f32 v[{T(k)}:{T(k) + 1}], v[{T(k)}:{T(k) + 1}], {f}, {t} op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]')
+        return
       for i in range(0, len(slots), len(temps)):
         part = slots[i:i + len(temps)]
         for t, k in zip(temps, part):
@@ -1175,10 +1234,13 @@ def gen(rb, wide=True, prof=False):
       for idx, t in enumerate(rem[:-1]):
         need_w()
         C = levels[level]
-        a(MUL() + f' {C[0]}, {F[0]}, {wv[t][0]}')
-        a(MUL() + f' {C[1]}, {F[0]}, {wv[t][1]}')
-        a(FMA() + f' {C[0]}, -{F[1]}, {wv[t][1]}, {C[0]}')
-        a(FMA() + f' {C[1]}, {F[1]}, {wv[t][0]}, {C[1]}')
+        if DT.wide:
+          a(MUL() + f' {C[0]}, {F[0]}, {wv[t][0]}')
+          a(MUL() + f' {C[1]}, {F[0]}, {wv[t][1]}')
+          a(FMA() + f' {C[0]}, -{F[1]}, {wv[t][1]}, {C[0]}')
+          a(FMA() + f' {C[1]}, {F[1]}, {wv[t][0]}, {C[1]}')
+        else:
+          pk_cmul(a, vpair(C[0]), vpair(F[0]), vpair(wv[t][0]), temps[0])
         visit(C, rem[idx + 1:], slot | (1 << others[t]), level + 1)
 
     visit((fr, fi), list(range(len(others))), 1 << j, 0)
