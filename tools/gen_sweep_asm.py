@@ -20,6 +20,10 @@ Register map (island-private, declared as clobbers to the compiler), complex128:
                         => 168 VGPRs at RB=5: THREE waves per SIMD
   s36..s99              scalar state (op header, gate matrix / group header,
                         cursors, masks, table entries)
+  s16..s23              header of the NEXT op (prefetched); s24,s25 = address of the handler table
+                        during the op loop (ops and DIAG-group apply code are reached by s_setpc_b64
+                        into a table of s_branch instructions; the host numbers the handlers:
+                        kernels_sweep.hip.h op_handler_id / group_handler_bits), store base at the end
 Operands supplied by the C++ kernel:
   %0,%1  tile base address lo,hi (SGPR)      %2  SweepParams* (SGPR pair)
   %3     tile index (idx_high|base) (SGPR pair, for outside-bit predicates)
@@ -240,7 +244,7 @@ def gen(rb, wide=True, prof=False):
     prof_rec(real_at=126)
   a('s_load_dwordx4 s[36:39], %2, 0x0')   # ops cursor, groups base
   a('s_load_dwordx2 s[40:41], %2, 0x10')  # oterms base
-  a('s_load_dwordx2 s[42:43], %2, 0x18')  # s42 = ops remaining, s43 = tables - groups (bytes)
+  a('s_load_dwordx2 s[42:43], %2, 0x18')  # s42 = number of ops (unused: a sentinel ends the list), s43 = tables - groups (bytes)
   tile_io(store=False)
   a('s_mov_b64 s[26:27], %3')                     # tile index at load time (see the store)
   a('s_load_dwordx8 s[16:23], s[36:37], 0x0')     # header of the first op
