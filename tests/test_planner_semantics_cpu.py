@@ -141,3 +141,30 @@ def test_reference_workload_plans_equal_the_oracle(oracle):
     got = psi.copy()
     plan_interp.run_plan(got, _planned(n, n, 0, stream), n)
     assert np.max(np.abs(got - want)) < 1e-11
+
+
+@pytest.mark.parametrize('bw', [128, 64])
+@pytest.mark.parametrize('env', [{}, {'QH_LANE_VALU': '2'}, {'QH_WAVE_BITS': '2'}, {'QH_BITFAC': '0'}],
+                         ids=['default', 'LANE_VALU=2', 'WAVE_BITS=2', 'BITFAC=0'])
+def test_qft_phase_ladders_become_factor_trees(oracle, monkeypatch, env, bw):
+  """A QFT's controlled-phase ladder between one register bit and the others is ONE group with bit factors
+  (DG_BITFAC, planner.h fuse_bit_factors); the plan still computes the QFT (QFT and inverse on random states, both
+  element widths' geometries, lane butterflies on either path, lane / wave exchanges left in place)."""
+  for k, v in env.items():
+    monkeypatch.setenv(k, v)
+  rng = np.random.default_rng(20 + bw)
+  for n in (13, 15):
+    qops, qg = workloads.qft_stream(range(n)).arrays()
+    stream = [([] if int(c) == NO_CTL else [int(c)], int(t), qg[k].view(np.complex128).copy()) for k, (c, t) in enumerate(qops)]
+    if n == 15:   # ... followed by the inverse circuit
+      stream = stream + [(c, t, np.conj(g.reshape(2, 2).T).reshape(4)) for c, t, g in reversed(stream)]
+    psi = rng.standard_normal(1 << n) + 1j * rng.standard_normal(1 << n)
+    psi = (psi / np.linalg.norm(psi)).astype(np.complex128)
+    want = psi.copy()
+    _oracle_apply(oracle, want, n, stream)
+    sweeps = _planned(n, n, 0, stream, bw=bw)
+    nbf = sum(1 for sp in sweeps for g in sp['groups'] if int(g['flags']) & plan_interp.DG_BITFAC)
+    assert (nbf == 0) if env.get('QH_BITFAC') == '0' else nbf >= 3, nbf
+    got = psi.copy()
+    plan_interp.run_plan(got, sweeps, n, 0)
+    assert float(np.max(np.abs(got - want))) < 1e-11
