@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void k_argmax(const typename AmpT<R>::type *__
   sp[threadIdx.x] = bp;
   si[threadIdx.x] = bi;
   __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
+  for (unsigned s = 128; s > 0; s >>= 1) {
     if (threadIdx.x < s) {
       const double op = sp[threadIdx.x + s];
       const uint64_t oi = si[threadIdx.x + s];

@@ -937,10 +937,6 @@ class Planner {
         swaps.pop_back();
       }
     };
-    auto lane_swapped = [&]() {
-      for (const Swap &w : swaps) if (!w.wave) return true;
-      return false;
-    };
     // the register bit to give up in an exchange: the one whose qubit is a dense target
     // again LATEST among the gates of this sweep (never, if possible) -- Belady
     size_t gi_now = 0;
