@@ -839,7 +839,7 @@ class Planner {
       if (o.kind == OP_WSWAP) lds += 256 * dw;      // 16 ds_write_b128 + 16 ds_read_b128, 8 cycles each
       else if (o.kind == OP_DENSE_LANE) lds += kLds;
     }
-    static const double floor_cycles = env_int("QH_LDS_FLOOR", 2500);
+    const double floor_cycles = env_int("QH_LDS_FLOOR", 2500);   // (read at every flush, like the other planner switches)
     LaneChoice ch;
     if (lds > floor_cycles) ch.dpp01 = ch.dpp23 = ch.lswap = ch.real01 = ch.real23 = 1 << 20;
     return ch;

@@ -15,7 +15,8 @@ SOURCES = [os.path.join(PKG, 'csrc', f) for f in
            ('engine.hip', 'kernels_gate.hip.h', 'kernels_sweep.hip.h', 'planner.h', 'exchange.hip.h',
             'sweep_island_rb2.inc', 'sweep_island_rb3.inc', 'sweep_island_rb4.inc',
             'sweep_island_rb5.inc', 'sweep_island_f32_rb2.inc', 'sweep_island_f32_rb3.inc',
-            'sweep_island_f32_rb4.inc', 'sweep_island_f32_rb5.inc', 'sweep_island_f32_rb6.inc', 'libq_facade.cc')]
+            'sweep_island_f32_rb4.inc', 'sweep_island_f32_rb5.inc', 'sweep_island_f32_rb6.inc', 'sweep_handlers.inc',
+            'libq_facade.cc')]
 HEADERS = [os.path.join(ROOT, 'include', 'libq.h')]
 HEADER = os.path.join(ROOT, 'include', 'qcc_hip.h')
 
