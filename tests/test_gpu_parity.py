@@ -523,3 +523,31 @@ def test_long_butterfly_runs_stay_in_range(oracle, bw):
     assert st.stats()['sweeps'] == 1
   assert np.all(np.isfinite(got))
   assert np.max(np.abs(got - want)) <= (1e-11 if bw == 128 else 2e-4)
+
+
+@pytest.mark.parametrize('bw', [128, 64])
+@pytest.mark.parametrize('lane_valu', ['1', '2'])
+def test_qft_of_random_states_small_tiles_vs_oracle(oracle, monkeypatch, bw, lane_valu):
+  """QFT and inverse QFT on random states of 8..17 qubits against the oracle: the phase ladders run as factor
+  trees (DG_BITFAC) on tiles with 2, 3, 4 and 5 (complex64: 6) register bits, whose handlers are separate code,
+  with the lane butterflies on either path."""
+  monkeypatch.setenv('QH_LANE_VALU', lane_valu)
+  rng = np.random.default_rng(77)
+  for n in range(8, 18):
+    ops, g8 = workloads.qft_stream(range(n)).arrays()
+    dt = np.complex128 if bw == 128 else np.complex64
+    psi0 = _rand_state(rng, n, dt)
+    want = psi0.astype(np.complex128)
+    oracle.run_stream(want, n, ops, g8)
+    with device.DeviceState(n, bw, fusion=native.QH_FUSE_SWEEP) as st:
+      st.upload(psi0)
+      st.run_stream(ops, g8)
+      got = st.download()
+      inv_ops = ops[::-1].copy()
+      z = g8[::-1].copy().view(np.complex128).reshape(-1, 2, 2)
+      gi = np.ascontiguousarray(np.conj(z.transpose(0, 2, 1))).view(np.float64).reshape(-1, 8)
+      st.run_stream(inv_ops, gi)
+      back = st.download()
+    tol = 1e-12 if bw == 128 else 2e-5
+    assert np.max(np.abs(got - want)) <= tol, (n, bw)
+    assert np.max(np.abs(back - psi0)) <= 2 * tol, (n, bw)
