@@ -341,6 +341,9 @@ class Planner {
   bool lanes_high_ = env_flag("QH_LANES_HIGH", true);
   int min_table_terms_ = env_int("QH_MIN_TABLE_TERMS", 2);
   bool bitfac_ = env_flag("QH_BITFAC", true);            // DG_BITFAC groups (fuse_bit_factors)
+  bool fold_sink_ = env_flag("QH_FOLD_SINK", true);      // the butterflies' scalars join a phase factor (emit_ops_with)
+  bool fold_pending_ = false;                            // ... still to be placed in the sweep being emitted
+  double fold_re_ = 1, fold_im_ = 0;
   int lane_valu_ = env_int("QH_LANE_VALU", 1);          // 0 never, 1 by cost model (choose_lane_paths), 2 always (tests)
   bool defer_diag_ = env_flag("QH_DEFER_DIAG", true);   // see build_sweep
   bool lookahead_ = env_flag("QH_RELAYOUT_AHEAD", true); // see finish_relayout
@@ -859,6 +862,7 @@ class Planner {
   }
 
   void emit_ops_with(const std::vector<const GateRec *> &taken, SweepPlan *sp, LaneChoice ch) {
+    fold_pending_ = false;
     // Butterflies (unit-entry gates c*M, see butterfly_variant): the scalars c are multiplied
     // into ONE uncontrolled dense gate of the sweep (a scalar commutes with everything) -- the
     // last one, which runs on the general path.  Without such a sink nothing is converted.
@@ -895,6 +899,15 @@ class Planner {
         }
         role[last] = 2;
         sink_re[last] = pr; sink_im[last] = pi;
+        // If the last gate is a butterfly itself, the whole product can ride on a phase factor that some DIAG
+        // op of the sweep applies to every amplitude anyway (flush_diag: a group without register mask): every
+        // such gate then costs additions only (supremacy: 400 FP64 instructions per tile less, QFT: 96).
+        if (fold_sink_ && butterflies_ && butterfly_variant(taken[last]->g) >= 0) {
+          role[last] = 1;
+          cmul_acc(&pr, &pi, taken[last]->g[0], taken[last]->g[1]);
+          fold_pending_ = true;
+          fold_re_ = pr; fold_im_ = pi;
+        }
       }
     }
     // current tile geometry: OP_LSWAP / OP_WSWAP exchange a lane / wave bit with a register bit on the fly
@@ -1086,6 +1099,17 @@ class Planner {
       }
     }
     flush_diag(&pending, ~0ull, sp, geom);
+    if (fold_pending_) {      // no DIAG op of the sweep had a factor for every amplitude: one of its own
+      SweepOp op{};
+      op.kind = OP_DIAG;
+      op.group_off = (uint32_t)sp->groups.size();
+      op.n_groups = 1;
+      DGroup g{};
+      g.re = fold_re_; g.im = fold_im_;
+      sp->groups.push_back(g);
+      sp->ops.push_back(op);
+      fold_pending_ = false;
+    }
     // Lane exchanges are undone (the lane -> address map of the store is fixed); wave
     // exchanges are not: the tile is stored where its amplitudes now belong (own slot
     // offsets, base corrected by the moved index bits) -- one LDS exchange less per wave bit.
@@ -1265,6 +1289,26 @@ class Planner {
       g.lane_mask = pg.lane; g.reg_mask = pg.reg; g.re = pg.re; g.im = pg.im;
       attach_outside(g, pg);
       sp->groups.push_back(g);
+    }
+    if (fold_pending_) {
+      // the butterflies' scalars (emit_ops_with): into a factor that reaches every lane and slot, if this op has one
+      DGroup *host = nullptr;
+      bool c_part = false;
+      for (size_t k = op.group_off; k < sp->groups.size(); ++k) {
+        DGroup &g = sp->groups[k];
+        if (g.reg_mask) continue;
+        c_part = true;
+        if (!host && ((g.flags & DG_LTAB) || g.lane_mask == 0)) host = &g;
+      }
+      if (host) {
+        cmul_acc(&host->re, &host->im, fold_re_, fold_im_);
+        fold_pending_ = false;
+      } else if (c_part) {
+        DGroup g{};
+        g.re = fold_re_; g.im = fold_im_;
+        sp->groups.push_back(g);
+        fold_pending_ = false;
+      }
     }
     fuse_bit_factors(sp, op.group_off, geom.rb);
     op.n_groups = (uint32_t)(sp->groups.size() - op.group_off);

@@ -48,8 +48,8 @@ def test_qft30_is_three_sweeps_and_accounts_every_gate():
   assert sw[1]['wavepos'] == [12] and sw[1]['lanehi'] == [13, 14, 15] and sw[1]['regpos'] == [16, 17, 18, 19, 20]
   assert sw[2]['wavepos'] == [12] and sw[2]['lanehi'] == [13, 14, 15] and sw[2]['regpos'] == [16, 17, 18, 19, 20]
   assert all(s['swept_bytes'] == 2 * S for s in sw)            # one read + one write each
-  # all H but one per sweep run as add-only butterflies; the remaining one carries the scalars
-  assert [s['butterfly_ops'] for s in sw] == [s['dense_ops'] - 1 for s in sw]
+  # every H runs as an add-only butterfly; their scalars ride on a phase factor of the sweep (planner.h: fold_sink_)
+  assert [s['butterfly_ops'] for s in sw] == [s['dense_ops'] for s in sw]
   # sweep 1 (contiguous tile) runs in place and stores the exchanged layout (one exchange); sweeps 2, 3
   # (split lanes) gather their tile and store it contiguously into the second buffer: the wave bit is
   # swapped into a register and the displaced bit once more, and nothing is swapped back
