@@ -90,8 +90,15 @@ int qh_destroy(qh_handle h);
 int qh_set_shard(qh_handle h, int nbits_global, uint64_t shard_index);
 /* Device pointer of the shard, amplitudes in physical order.  A handle that owns its memory may
  * re-lay the state out between two buffers while sweeps run (planner.h, relayout): this call
- * brings it back to canonical order first and the pointer is valid until the next gate.      */
+ * brings it back to canonical order first and, from then on, keeps the state in that one buffer
+ * (as qh_set_relayout(h, 0) does): the pointer stays valid for the life of the handle.        */
 int qh_device_ptr(qh_handle h, void **ptr);
+/* Relayout sweeps (a second buffer of the state's size; planner.h): on = 1 allocates it now, on = 0 runs what is
+ * queued, returns the layout to canonical order and frees it.  *actual (may be NULL) = the resulting mode.
+ * Default: decided at the first flush (on if the handle owns its memory and the buffer fits).  A handle with a
+ * communicator of SEVERAL ranks starts with relayout off: every rank must hold the same layout when they exchange,
+ * so the caller turns it on only after all ranks report that they can (qcc_amd/sharded.py).                  */
+int qh_set_relayout(qh_handle h, int on, int *actual);
 int qh_stream(qh_handle h, void **stream);
 int qh_nbits(qh_handle h, int *nbits_local, int *nbits_global);
 
@@ -121,6 +128,12 @@ int qh_applyc(qh_handle h, int ctl, int tgt, const double gate[8]);
  * multi-controlled gates.                                                    */
 int qh_apply_bits(qh_handle h, uint64_t ctl_mask, int tgt_bit,
                   const double gate[8]);
+
+/* The whole stream in one call: ops[2k] = control qubit of gate k or QH_NO_CTL (then qh_apply1), ops[2k+1] =
+ * target qubit, gates + 8k = its 8 doubles -- exactly `count` qh_apply1/qh_applyc calls (xgates.cc:89-145), without
+ * the per-call cost of the host language's FFI (ctypes: ~3 us per gate).  Stops at the first error.          */
+#define QH_NO_CTL INT32_MIN
+int qh_apply_stream(qh_handle h, uint64_t count, const int32_t *ops, const double *gates);
 
 int qh_set_fusion(qh_handle h, int level);
 /* Launch everything queued (no-op with QH_FUSE_OFF).                         */
@@ -170,6 +183,8 @@ typedef struct {
   uint64_t slabs;            /* slabs the exchanges were cut into                          */
   uint64_t sweeps_overlapped;/* sweeps launched slab-wise around exchanges                 */
   double span_ms;            /* HIP-event time from the first send to the last landing     */
+  uint64_t rounds_packed;    /* rounds moved through the gather / scatter kernels (blocks
+                                without long contiguous runs: after relayout sweeps)       */
 } qh_xstats;
 int qh_comm_unique_id(void *id /* QH_COMM_ID_BYTES, rank 0; broadcast by the caller */);
 int qh_comm_init(qh_handle h, int nranks, int rank, const void *id);

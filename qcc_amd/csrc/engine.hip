@@ -57,6 +57,7 @@ struct qh_state_s {
   void *d_alt = nullptr;       // second buffer of the same size: target of relayout sweeps (lazily allocated)
   int relayout = -1;           // -1 undecided, 0 off (attached memory, no room, QH_RELAYOUT=0), 1 on
   bool owns_mem = false, owns_stream = false, dry = false;
+  bool poisoned = false;       // a sweep of a flush failed after others had run: the amplitudes are undefined until re-initialised
   hipStream_t stream = nullptr;
   int fusion = QH_FUSE_OFF;
   int perm[64];  // physical bit of logical bit
@@ -270,23 +271,37 @@ int use_device(qh_state_s *h) {
   return QH_OK;
 }
 
-// Sweeps may re-lay the state out into a second buffer (planner.h, Planner::relayout) when the
-// handle owns its memory, takes part in no exchange, and a second buffer of the same size fits.
-bool relayout_ready(qh_state_s *h) {
+// Sweeps may re-lay the state out into a second buffer (planner.h, Planner::relayout) when the handle owns its
+// memory and a second buffer of the same size fits.  A handle with a communicator of more than one rank only
+// does so after qh_set_relayout(h, 1) -- the ranks must agree (an exchange needs the same layout everywhere),
+// and only the caller can ask them all.
+bool relayout_eligible(const qh_state_s *h) {
+  return env_int("QH_RELAYOUT", 1) != 0 && h->owns_mem && !h->host_psi && qh::sweep_supported(h->nloc, h->bw);
+}
+// what a flush would get, without allocating anything (plans shown by qh_plan_json / qh_plan_export)
+bool relayout_wanted(const qh_state_s *h) {
   if (h->dry) return env_int("QH_RELAYOUT", 1) != 0;      // planner-only handles: plan what a real handle would
+  if (h->relayout >= 0) return h->relayout == 1;
+  return relayout_eligible(h) && !(h->comm && h->comm->nranks > 1);
+}
+bool alloc_second_buffer(qh_state_s *h) {
+  if (h->d_alt) return true;
+  const size_t bytes = (size_t)h->amp_bytes() << h->nloc;
+  size_t fr = 0, total = 0;
+  if (hipMemGetInfo(&fr, &total) == hipSuccess && fr > bytes + (bytes >> 5) + (3ull << 29) &&
+      hipMalloc(&h->d_alt, bytes) == hipSuccess)
+    return true;
+  (void)hipGetLastError();
+  h->d_alt = nullptr;
+  return false;
+}
+bool relayout_ready(qh_state_s *h) {
+  if (h->dry) return relayout_wanted(h);
   if (h->relayout < 0) {
     h->relayout = 0;
-    if (env_int("QH_RELAYOUT", 1) != 0 && h->owns_mem && !h->comm && qh::sweep_supported(h->nloc, h->bw)) {
-      const size_t bytes = (size_t)h->amp_bytes() << h->nloc;
-      size_t fr = 0, total = 0;
-      if (hipMemGetInfo(&fr, &total) == hipSuccess && fr > bytes + (bytes >> 4) + (1ull << 30) &&
-          hipMalloc(&h->d_alt, bytes) == hipSuccess)
-        h->relayout = 1;
-      else
-        (void)hipGetLastError();
-    }
+    if (relayout_eligible(h) && !(h->comm && h->comm->nranks > 1) && alloc_second_buffer(h)) h->relayout = 1;
   }
-  return h->relayout == 1 && !h->comm;
+  return h->relayout == 1;
 }
 
 bool layout_is_canonical(const qh_state_s *h) {
@@ -332,6 +347,9 @@ int canonicalize(qh_state_s *h) {
 int flush_impl(qh_state_s *h, qh::SlabIO *split = nullptr) {
   int rc = use_device(h);
   if (rc) return rc;
+  if (h->poisoned)
+    return fail(QH_ERR_HIP, "the state of this handle is undefined: a sweep of an earlier flush failed after others had run; "
+                            "re-initialise it (qh_init_basis / qh_init_product / qh_upload of the whole shard)");
   std::vector<qh::Arrival> *arr = (h->comm && !h->comm->arrivals.empty()) ? &h->comm->arrivals : nullptr;
   if (h->queue.empty()) {
     qh::wait_all_arrivals(arr, h->stream);   // whoever called touches the state next
@@ -343,11 +361,12 @@ int flush_impl(qh_state_s *h, qh::SlabIO *split = nullptr) {
     qh::SlabIO *io = split ? split : &local;
     io->arrivals = arr;
     io->comm = h->comm;
-    const bool relay = !split && relayout_ready(h);
+    const bool relay = relayout_ready(h);
     void *result = h->d_psi;
     uint8_t final_pos[64];
     rc = qh::run_fused(h->queue, h->nloc, h->shard, h->bw, h->d_psi, h->stream, h->dry,
-                       &h->sweep, &h->stats, &g_err, h->comm ? io : nullptr, h->d_alt, relay, &result, final_pos);
+                       &h->sweep, &h->stats, &g_err, h->comm ? io : nullptr, h->d_alt, relay, &result, final_pos,
+                       h->nglob > h->nloc);
     if (rc == QH_OK && relay) {
       if (result != h->d_psi) std::swap(h->d_psi, h->d_alt);
       for (int b = 0; b < h->nglob; ++b)
@@ -357,7 +376,10 @@ int flush_impl(qh_state_s *h, qh::SlabIO *split = nullptr) {
     if (h->comm) h->comm->stats.sweeps_overlapped += io->sweeps_overlapped;
     if (rc != QH_OK && h->stats.kernels_launched == launched0) return rc;   // nothing ran: queue kept
     if (rc == QH_OK) rc = check_launch(h);
-    if (rc != QH_OK) g_err += " [sweeps of this flush may have run partially; its gates were dropped]";
+    if (rc != QH_OK) {
+      g_err += " [sweeps of this flush may have run partially: its gates were dropped and the state is undefined until re-initialised]";
+      h->poisoned = true;
+    }
     h->queue.clear();
     return rc;
   }
@@ -371,6 +393,32 @@ int flush_impl(qh_state_s *h, qh::SlabIO *split = nullptr) {
   }
   h->queue.erase(h->queue.begin(), h->queue.begin() + done);
   return rc;
+}
+
+// on: allocate the second buffer now (false if it does not fit); off: queued gates run, the layout returns to
+// canonical order, the second buffer is freed.  *actual (optional) = the resulting mode.
+int set_relayout(qh_state_s *h, bool on, int *actual = nullptr) {
+  if (h->dry) {
+    if (actual) *actual = relayout_wanted(h) ? 1 : 0;
+    return QH_OK;
+  }
+  int rc = use_device(h);
+  if (rc) return rc;
+  if (on) {
+    if (h->relayout != 1) h->relayout = (relayout_eligible(h) && alloc_second_buffer(h)) ? 1 : 0;
+  } else {
+    rc = flush_impl(h);
+    if (rc == QH_OK) rc = canonicalize(h);
+    if (rc) return rc;
+    if (h->d_alt) {
+      HIP_TRY(hipStreamSynchronize(h->stream));
+      (void)hipFree(h->d_alt);
+      h->d_alt = nullptr;
+    }
+    h->relayout = 0;
+  }
+  if (actual) *actual = h->relayout == 1 ? 1 : 0;
+  return QH_OK;
 }
 
 int submit_phys(qh_state_s *h, uint64_t cmask, int tbit, const double g[8]) {
@@ -614,9 +662,11 @@ int qh_set_shard(qh_handle h, int nbits_global, uint64_t shard_index) {
 
 int qh_device_ptr(qh_handle h, void **ptr) {
   if (!h || !ptr) return fail(QH_ERR_ARG, "null");
-  if (!h->dry && !layout_is_canonical(h)) {   // the caller reads amplitudes in physical order
-    int rc = flush_impl(h);
-    if (rc == QH_OK) rc = canonicalize(h);
+  if (!h->dry) {
+    // the caller will address amplitudes in physical order through this pointer for as long as it likes: run
+    // what is queued, bring the layout back to canonical order, and stop re-laying the state out (a later
+    // relayout sweep would swap the two buffers under the caller: ADVICE r2)
+    int rc = set_relayout(h, false);
     if (rc) return rc;
   }
   *ptr = h->d_psi;
@@ -674,6 +724,7 @@ int qh_init_basis(qh_handle h, uint64_t index) {
   if (!h) return fail(QH_ERR_ARG, "null handle");
   if (h->nglob < 64 && (index >> h->nglob)) return fail(QH_ERR_ARG, "basis index out of range");
   h->queue.clear();
+  h->poisoned = false;
   if (h->dry) return QH_OK;
   HIP_TRY(hipSetDevice(h->device));
   if (h->comm) qh::wait_all_arrivals(&h->comm->arrivals, h->stream);
@@ -717,6 +768,7 @@ int qh_init_product(qh_handle h, int nfactors, const int *nq, const double *cons
   if (total != h->nglob) return fail(QH_ERR_ARG, "factor sizes do not add up to the number of qubits");
   if (entries > (1ull << 25)) return fail(QH_ERR_ARG, "factor tables larger than 2^25 amplitudes");
   h->queue.clear();
+  h->poisoned = false;
   if (h->dry) return QH_OK;
   if (h->comm) qh::wait_all_arrivals(&h->comm->arrivals, h->stream);
   std::vector<double> tab(2 * std::max<uint64_t>(entries, 1));
@@ -756,6 +808,10 @@ int qh_upload(qh_handle h, const void *host, uint64_t offset, uint64_t count) {
   if (!h || !host || h->dry) return fail(QH_ERR_ARG, "null/dry");
   if (offset + count > (1ull << h->nloc)) return fail(QH_ERR_ARG, "upload range out of bounds");
   HIP_TRY(hipSetDevice(h->device));
+  if (offset == 0 && count == (1ull << h->nloc) && h->poisoned) {   // the whole shard is replaced: a fresh start
+    h->queue.clear();
+    h->poisoned = false;
+  }
   int rc = flush_impl(h);
   if (rc == QH_OK) rc = canonicalize(h);
   if (rc) return rc;
@@ -864,6 +920,24 @@ int qh_sync(qh_handle h) {
   int rc = flush_impl(h);
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(h->stream));
+  return QH_OK;
+}
+
+int qh_set_relayout(qh_handle h, int on, int *actual) {
+  if (!h) return fail(QH_ERR_ARG, "null handle");
+  return set_relayout(h, on != 0, actual);
+}
+
+int qh_apply_stream(qh_handle h, uint64_t count, const int32_t *ops, const double *gates) {
+  if (!h || (count && (!ops || !gates))) return fail(QH_ERR_ARG, "null");
+  for (uint64_t k = 0; k < count; ++k) {
+    const int32_t c = ops[2 * k], t = ops[2 * k + 1];
+    const int rc = c == INT32_MIN ? qh_apply1(h, t, gates + 8 * k) : qh_applyc(h, c, t, gates + 8 * k);
+    if (rc) {
+      g_err = "gate " + std::to_string(k) + " of the stream: " + g_err;
+      return rc;
+    }
+  }
   return QH_OK;
 }
 
@@ -1021,7 +1095,7 @@ int qh_timer_end(qh_handle h, float *ms) {
 int qh_plan_json(qh_handle h, char *buf, uint64_t cap, uint64_t *needed) {
   if (!h) return fail(QH_ERR_ARG, "null");
   std::string s = qh::plan_to_json(h->queue, h->nloc, h->shard, h->bw, qh::sweep_max_rb(),
-                                   qh::sweep_split_lanes(), relayout_ready(h));
+                                   qh::sweep_split_lanes(), relayout_wanted(h), h->nglob > h->nloc);
   if (needed) *needed = s.size() + 1;
   if (buf && cap) {
     const uint64_t n = std::min<uint64_t>(cap - 1, s.size());
@@ -1035,7 +1109,7 @@ int qh_plan_export(qh_handle h, void *buf, uint64_t cap, uint64_t *needed) {
   if (!h) return fail(QH_ERR_ARG, "null");
   if (!qh::sweep_supported(h->nloc, h->bw)) return fail(QH_ERR_ARG, "state too small for sweeps");
   qh::PlanResult pr = qh::plan_best(h->queue, h->nloc, h->shard, h->bw, qh::sweep_max_rb(),
-                                    qh::sweep_split_lanes(), relayout_ready(h));
+                                    qh::sweep_split_lanes(), relayout_wanted(h), h->nglob > h->nloc);
   std::vector<uint64_t> out;
   auto put_bytes = [&](const void *p, size_t n) {
     const size_t w = (n + 7) / 8, at = out.size();
@@ -1112,18 +1186,25 @@ int comm_common_init(qh_state_s *h, int nranks, int rank) {
   if (h->comm) return fail(QH_ERR_ARG, "handle already has a communicator");
   if (nranks < 1 || (nranks & (nranks - 1)) || rank < 0 || rank >= nranks)
     return fail(QH_ERR_ARG, "nranks %d must be a power of two, rank %d inside it", nranks, rank);
+  if (nranks > qh::kMaxXferMoves + 1) return fail(QH_ERR_ARG, "at most %d ranks", qh::kMaxXferMoves + 1);
   if (h->bw != 128 && h->bw != 64) return fail(QH_ERR_BAD_DTYPE, "bit width");
   HIP_TRY(hipSetDevice(h->device));
-  // exchanges address PHYSICAL index bits: from here on sweeps stay in place, so bring the state
-  // back to canonical order if earlier flushes re-laid it out
   int rc0 = flush_impl(h);
-  if (rc0 == QH_OK) rc0 = canonicalize(h);
   if (rc0) return rc0;
+  if (nranks > 1 && h->relayout != 0) {
+    // The ranks of a sharded state must hold the same layout whenever they exchange.  They do if all of them
+    // re-lay out (the planner keeps rank-dependent gates as ghosts: planner.h) or none does; a rank that could
+    // not get its second buffer would break that, so with several ranks relayout starts OFF and the caller
+    // turns it on after every rank has said it can (qh_set_relayout; qcc_amd/sharded.py does).
+    rc0 = set_relayout(h, false);
+    if (rc0) return rc0;
+  }
   auto *c = new qh::Comm;
   c->nranks = nranks;
   c->rank = rank;
   hipError_t e = hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->cstream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->pstream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreate(&c->t0);
   if (e == hipSuccess) e = hipEventCreate(&c->t1);
   if (e != hipSuccess) {
@@ -1143,30 +1224,94 @@ void close_timing(qh::Comm *c) {
   c->timing_open = false;
 }
 
-// The exchange proper.  `moves`: block value blk of the g bits at `base` goes to `peer`, whose
-// data lands in block value `land`.
+template <typename A>
+void launch_xfer(bool unpack, void *psi, void *stage, uint64_t n, uint64_t start, const qh::XferGeom &g, hipStream_t st) {
+  const uint64_t total = n * (uint64_t)g.np;
+  const unsigned grid = (unsigned)std::min<uint64_t>((total + 255) / 256, 1ull << 20);
+  if (unpack) hipLaunchKernelGGL(qh::k_xunpack<A>, dim3(grid), dim3(256), 0, st, (A *)psi, (const A *)stage, n, start, g);
+  else hipLaunchKernelGGL(qh::k_xpack<A>, dim3(grid), dim3(256), 0, st, (const A *)psi, (A *)stage, n, start, g);
+}
+
+// Every rank must cut an exchange the same way (rounds, chunk sizes, slabs, where each index bit lives): the
+// geometry is a function of rank-invariant inputs only -- the planner keeps rank-dependent gates as ghosts, so
+// plans, tiles and layouts agree by construction -- and this is the check of that claim: a 64-bit signature of
+// the geometry is compared with every peer's (always on the host-staged transport; on RCCL with
+// QH_EXCHANGE_VERIFY=1, a host wait).  A mismatch is an error here instead of a hang or misplaced data there.
+int verify_geometry(qh_state_s *h, uint64_t sig) {
+  qh::Comm *c = h->comm;
+  if (c->nranks <= 1) return QH_OK;
+  if (c->custom) {
+    const int np = c->nranks - 1;
+    std::vector<uint64_t> mine(np, sig), theirs(np, 0);
+    std::vector<int> peers;
+    std::vector<void *> sp, rp;
+    for (int j = 0, k = 0; j < c->nranks; ++j) {
+      if (j == c->rank) continue;
+      peers.push_back(j);
+      sp.push_back(&mine[k]);
+      rp.push_back(&theirs[k]);
+      ++k;
+    }
+    if (c->custom(c->custom_user, np, peers.data(), sp.data(), rp.data(), sizeof(uint64_t)) != 0)
+      return fail(QH_ERR_COMM, "host-staged transport: the round callback failed (geometry check)");
+    for (int k = 0; k < np; ++k)
+      if (theirs[k] != sig)
+        return fail(QH_ERR_COMM, "exchange geometry differs between rank %d (%016llx) and rank %d (%016llx): the ranks "
+                    "planned different sweeps or layouts", c->rank, (unsigned long long)sig, peers[k], (unsigned long long)theirs[k]);
+    return QH_OK;
+  }
+  if (!env_int("QH_EXCHANGE_VERIFY", 0)) return QH_OK;
+  double v[4] = {(double)(sig >> 32), (double)(sig & 0xffffffffu), -(double)(sig >> 32), -(double)(sig & 0xffffffffu)};
+  HIP_TRY(hipMemcpyAsync(h->d_red, v, sizeof v, hipMemcpyHostToDevice, h->stream));
+  NCCL_TRY(qh::rccl().AllReduce(h->d_red, h->d_red, 4, ncclDouble, ncclMax, c->nccl, h->stream));
+  double w[4];
+  HIP_TRY(hipMemcpyAsync(w, h->d_red, sizeof w, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (w[0] != -w[2] || w[1] != -w[3])
+    return fail(QH_ERR_COMM, "exchange geometry differs between ranks (signature of rank %d: %016llx)", c->rank, (unsigned long long)sig);
+  return QH_OK;
+}
+
+// The exchange proper.  `moves`: block value blk of the g LOGICAL local bits [base, base+g) goes to `peer`,
+// whose data lands in block value `land`.  Logical = the bit numbers the caller uses (canonical positions);
+// where those bits live now is the handle's business (relayout sweeps move them).
 int do_exchange(qh_state_s *h, const std::vector<qh::BlockMove> &moves, int base, int gbits, uint64_t chunk_amps) {
   qh::Comm *c = h->comm;
   const int nloc = h->nloc;
   const uint64_t ab = h->amp_bytes();
-  if (base < 0 || base + gbits > nloc) return fail(QH_ERR_BAD_QUBIT, "exchange bits [%d,%d) outside the %d local bits", base, base + gbits, nloc);
+  if (base < 0 || base + gbits > h->nglob || gbits > 8) return fail(QH_ERR_BAD_QUBIT, "exchange bits [%d,%d)", base, base + gbits);
+  for (int k = 0; k < gbits; ++k)
+    if (h->perm[base + k] >= nloc) return fail(QH_ERR_BAD_QUBIT, "exchange bit %d is not a local bit of this shard", base + k);
+  if (moves.size() > (size_t)qh::kMaxXferMoves) return fail(QH_ERR_ARG, "too many peers");
   HIP_TRY(hipSetDevice(h->device));
   close_timing(c);
   // 1. the queued gates, the last sweep cut into slabs
-  const uint64_t blockbits = ((1ull << gbits) - 1) << base;
   qh::SlabIO io;
   io.split_last = true;
-  io.avoid = blockbits;
+  for (int k = 0; k < gbits; ++k) io.avoid |= 1ull << h->perm[base + k];   // (layout before the flush; run_fused follows the moves)
   io.want_bits = env_int("QH_EXCHANGE_SLAB_BITS", 3);
   c->pool_used = 0;   // (arrivals of the previous exchange are waited for by this flush)
   int rc = flush_impl(h, &io);
   if (rc) return rc;
+  // 2. where the blocks' bits live now
+  int pos[8];
+  uint64_t blockbits = 0;
+  for (int k = 0; k < gbits; ++k) { pos[k] = h->perm[base + k]; blockbits |= 1ull << pos[k]; }
+  auto blk_off = [&](int v) {
+    uint64_t o = 0;
+    for (int k = 0; k < gbits; ++k) if ((v >> k) & 1) o |= 1ull << pos[k];
+    return o;
+  };
   uint64_t slab_mask = io.slab_mask;
-  if (!slab_mask && io.want_bits > 0) {
-    // nothing was queued (or the last sweep could not be cut): slabs still let the NEXT sweep start early
-    slab_mask = qh::pick_slab_bits(nloc, blockbits | 7ull, std::min(io.want_bits, std::max(0, nloc - gbits - 10)), 6);
+  std::vector<uint64_t> slab_vals = io.slab_vals;
+  if (io.slab_done.empty()) {
+    slab_mask = 0;
+    if (io.want_bits > 0)   // nothing was queued (or the last sweep could not be cut): slabs still let the NEXT sweep start early
+      slab_mask = qh::pick_slab_bits(nloc, blockbits | 7ull, std::min(io.want_bits, std::max(0, nloc - gbits - 10)), 6);
+    slab_vals.clear();
+    for (int k = 0; k < (1 << qh::popc(slab_mask)); ++k) slab_vals.push_back(qh::deposit_bits((uint64_t)k, slab_mask));
   }
-  const int K = 1 << qh::popc(slab_mask);
+  const int K = (int)slab_vals.size();
   hipEvent_t all_done = nullptr;
   if (io.slab_done.empty() || std::find(io.slab_done.begin(), io.slab_done.end(), nullptr) != io.slab_done.end()) {
     all_done = c->event();
@@ -1174,17 +1319,66 @@ int do_exchange(qh_state_s *h, const std::vector<qh::BlockMove> &moves, int base
     HIP_TRY(hipEventRecord(all_done, h->stream));
     io.slab_done.assign(K, all_done);
   }
-  // 2. geometry of the rounds
+  // 3. geometry of the rounds.  Two ways to move a round: DIRECT -- the blocks are contiguous runs of the shard,
+  // sent from where they lie and copied home from the staging area -- when the low free bits give runs of at
+  // least 4 MiB; PACKED -- a gather kernel packs each peer's amplitudes of the round into the staging area, a
+  // scatter kernel puts the received ones in place -- whatever the layout (after relayout sweeps the blocks'
+  // bits may sit anywhere above the 128-byte line).
   const uint64_t free_mask = h->local_mask() & ~blockbits & ~slab_mask;
+  const int nfree = qh::popc(free_mask);
   const int run_bits = (~free_mask) ? __builtin_ctzll(~free_mask) : 64;
   if (!chunk_amps) chunk_amps = 1ull << 22;
-  int chunk_bits = 0;
-  while ((2ull << chunk_bits) <= chunk_amps && chunk_bits + 1 <= run_bits) chunk_bits++;
+  int want_bits = 0;
+  while ((2ull << want_bits) <= chunk_amps && want_bits + 1 <= nfree) want_bits++;
+  const int force = env_int("QH_EXCHANGE_PACK", -1);      // tests: 1 = always packed, 0 = never
+  const bool packed = force >= 0 ? force != 0 : run_bits < std::min(want_bits, 18);
+  const int chunk_bits = packed ? want_bits : std::min(want_bits, run_bits);
   const uint64_t n = 1ull << chunk_bits;                       // amplitudes per peer and round
-  const uint64_t nchunks = 1ull << (qh::popc(free_mask) - chunk_bits);
+  const uint64_t nchunks = 1ull << (nfree - chunk_bits);
   const size_t np = moves.size();
   if (np == 0) return QH_OK;
+  {
+    uint64_t sig = 0x9e3779b97f4a7c15ull;
+    auto mix = [&](uint64_t v) { sig ^= v + 0x9e3779b97f4a7c15ull + (sig << 6) + (sig >> 2); };
+    for (int b = 0; b < h->nglob; ++b) mix((uint64_t)h->perm[b]);
+    mix(slab_mask); mix((uint64_t)chunk_bits); mix(nchunks); mix(packed); mix((uint64_t)K); mix(blockbits); mix((uint64_t)base); mix((uint64_t)gbits);
+    for (uint64_t v : slab_vals) mix(v);
+    rc = verify_geometry(h, sig);
+    if (rc) return rc;
+  }
   char *psi = (char *)h->d_psi;
+  qh::XferGeom xg_send{}, xg_land{};
+  if (packed) {
+    qh::BitIns ins{};
+    for (int b = 0; b < nloc; ++b) if (!((free_mask >> b) & 1ull)) {
+      if (ins.n == qh::kMaxIns) return fail(QH_ERR_ARG, "exchange: more than %d block + slab bits", qh::kMaxIns);
+      ins.pos[ins.n++] = b;
+    }
+    xg_send.ins = xg_land.ins = ins;
+    xg_send.np = xg_land.np = (int)np;
+    for (size_t m = 0; m < np; ++m) { xg_send.off[m] = blk_off(moves[m].blk); xg_land.off[m] = blk_off(moves[m].land); }
+  }
+  // staging: [2 receive halves][2 send halves (packed only)] of (peers x chunk) amplitudes
+  const size_t half = np * n * ab;
+  const size_t need_stage = (packed ? 4 : 2) * half;
+  if (c->staging_bytes < need_stage && (packed || !c->custom)) {
+    if (c->staging) {
+      HIP_TRY(hipStreamSynchronize(c->cstream));
+      HIP_TRY(hipStreamSynchronize(c->pstream));
+      HIP_TRY(hipStreamSynchronize(c->xstream));
+      (void)hipFree(c->staging);
+      c->staging = nullptr;
+      c->staging_bytes = 0;
+    }
+    HIP_TRY(hipMalloc(&c->staging, need_stage));
+    c->staging_bytes = need_stage;
+  }
+  auto xfer = [&](bool unpack, void *stage, uint64_t start, uint64_t sv, hipStream_t st) {
+    qh::XferGeom g = unpack ? xg_land : xg_send;
+    for (size_t m = 0; m < np; ++m) g.off[m] |= sv;
+    if (h->bw == 128) launch_xfer<double2>(unpack, psi, stage, n, start, g, st);
+    else launch_xfer<float2>(unpack, psi, stage, n, start, g, st);
+  };
   if (c->custom) {
     // host-staged transport: synchronous rounds
     const size_t need = np * n * ab;
@@ -1205,18 +1399,29 @@ int do_exchange(qh_state_s *h, const std::vector<qh::BlockMove> &moves, int base
       rp[m] = (char *)c->h_recv + m * n * ab;
     }
     for (int k = 0; k < K; ++k) {
-      const uint64_t sv = qh::deposit_bits((uint64_t)k, slab_mask);
+      const uint64_t sv = slab_vals[k];
       HIP_TRY(hipEventSynchronize(io.slab_done[k]));
       if (k == 0) { HIP_TRY(hipEventRecord(c->t0, c->xstream)); }
       for (uint64_t ci = 0; ci < nchunks; ++ci) {
-        const uint64_t off = qh::deposit_bits(ci << chunk_bits, free_mask) | sv;
-        for (size_t m = 0; m < np; ++m)
-          HIP_TRY(hipMemcpyAsync(sp[m], psi + (off | ((uint64_t)moves[m].blk << base)) * ab, n * ab, hipMemcpyDeviceToHost, c->xstream));
+        if (packed) {
+          xfer(false, c->staging, ci << chunk_bits, sv, c->xstream);
+          HIP_TRY(hipMemcpyAsync(c->h_send, c->staging, need, hipMemcpyDeviceToHost, c->xstream));
+        } else {
+          const uint64_t off = qh::deposit_bits(ci << chunk_bits, free_mask) | sv;
+          for (size_t m = 0; m < np; ++m)
+            HIP_TRY(hipMemcpyAsync(sp[m], psi + (off | blk_off(moves[m].blk)) * ab, n * ab, hipMemcpyDeviceToHost, c->xstream));
+        }
         HIP_TRY(hipStreamSynchronize(c->xstream));
         if (c->custom(c->custom_user, (int)np, peers.data(), sp.data(), rp.data(), n * ab) != 0)
           return fail(QH_ERR_COMM, "host-staged transport: the round callback failed");
-        for (size_t m = 0; m < np; ++m)
-          HIP_TRY(hipMemcpyAsync(psi + (off | ((uint64_t)moves[m].land << base)) * ab, rp[m], n * ab, hipMemcpyHostToDevice, c->xstream));
+        if (packed) {
+          HIP_TRY(hipMemcpyAsync(c->staging, c->h_recv, need, hipMemcpyHostToDevice, c->xstream));
+          xfer(true, c->staging, ci << chunk_bits, sv, c->xstream);
+        } else {
+          const uint64_t off = qh::deposit_bits(ci << chunk_bits, free_mask) | sv;
+          for (size_t m = 0; m < np; ++m)
+            HIP_TRY(hipMemcpyAsync(psi + (off | blk_off(moves[m].land)) * ab, rp[m], n * ab, hipMemcpyHostToDevice, c->xstream));
+        }
         HIP_TRY(hipStreamSynchronize(c->xstream));
         c->stats.rounds++;
       }
@@ -1227,47 +1432,52 @@ int do_exchange(qh_state_s *h, const std::vector<qh::BlockMove> &moves, int base
     }
     HIP_TRY(hipEventRecord(c->t1, c->xstream));
   } else {
-    // RCCL: grouped send/recv per round on xstream, landing copies on cstream, two staging halves
+    // RCCL: grouped send/recv per round on xstream, landing (copies / scatter kernel) on cstream, packing on pstream
     if (!c->nccl) return fail(QH_ERR_COMM, "no communicator (qh_comm_init)");
-    const size_t half = np * n * ab;
-    if (c->staging_bytes < 2 * half) {
-      if (c->staging) {
-        HIP_TRY(hipStreamSynchronize(c->cstream));
-        (void)hipFree(c->staging);
-        c->staging = nullptr;
-        c->staging_bytes = 0;
-      }
-      HIP_TRY(hipMalloc(&c->staging, 2 * half));
-      c->staging_bytes = 2 * half;
-    }
     const ncclDataType_t dt = h->bw == 128 ? ncclDouble : ncclFloat;
     const size_t cnt = (size_t)n * 2;
     auto &R = qh::rccl();
-    hipEvent_t copied[2] = {nullptr, nullptr};
+    hipEvent_t copied[2] = {nullptr, nullptr};   // receive half free again
+    hipEvent_t sent[2] = {nullptr, nullptr};     // send half free again (packed)
     uint64_t round = 0;
     for (int k = 0; k < K; ++k) {
-      const uint64_t sv = qh::deposit_bits((uint64_t)k, slab_mask);
-      HIP_TRY(hipStreamWaitEvent(c->xstream, io.slab_done[k], 0));
-      if (k == 0) { HIP_TRY(hipEventRecord(c->t0, c->xstream)); }
+      const uint64_t sv = slab_vals[k];
+      HIP_TRY(hipStreamWaitEvent(packed ? c->pstream : c->xstream, io.slab_done[k], 0));
+      if (k == 0) { HIP_TRY(hipEventRecord(c->t0, packed ? c->pstream : c->xstream)); }
       hipEvent_t last_copy = nullptr;
       for (uint64_t ci = 0; ci < nchunks; ++ci, ++round) {
         const int par = (int)(round & 1);
         const uint64_t off = qh::deposit_bits(ci << chunk_bits, free_mask) | sv;
         char *stage = (char *)c->staging + par * half;
+        char *sstage = (char *)c->staging + (2 + par) * half;
+        if (packed) {
+          if (sent[par]) HIP_TRY(hipStreamWaitEvent(c->pstream, sent[par], 0));
+          xfer(false, sstage, ci << chunk_bits, sv, c->pstream);
+          hipEvent_t pk = c->event();
+          if (!pk) return fail(QH_ERR_HIP, "hipEventCreate failed");
+          HIP_TRY(hipEventRecord(pk, c->pstream));
+          HIP_TRY(hipStreamWaitEvent(c->xstream, pk, 0));
+        }
         if (copied[par]) HIP_TRY(hipStreamWaitEvent(c->xstream, copied[par], 0));   // this half is free again
         NCCL_TRY(R.GroupStart());
         for (size_t m = 0; m < np; ++m) {
-          NCCL_TRY(R.Send(psi + (off | ((uint64_t)moves[m].blk << base)) * ab, cnt, dt, moves[m].peer, c->nccl, c->xstream));
+          const void *src = packed ? (const void *)(sstage + m * n * ab) : (const void *)(psi + (off | blk_off(moves[m].blk)) * ab);
+          NCCL_TRY(R.Send(src, cnt, dt, moves[m].peer, c->nccl, c->xstream));
           NCCL_TRY(R.Recv(stage + m * n * ab, cnt, dt, moves[m].peer, c->nccl, c->xstream));
         }
         NCCL_TRY(R.GroupEnd());
         hipEvent_t landed = c->event();
         if (!landed) return fail(QH_ERR_HIP, "hipEventCreate failed");
         HIP_TRY(hipEventRecord(landed, c->xstream));
+        sent[par] = landed;
         HIP_TRY(hipStreamWaitEvent(c->cstream, landed, 0));
-        for (size_t m = 0; m < np; ++m)
-          HIP_TRY(hipMemcpyAsync(psi + (off | ((uint64_t)moves[m].land << base)) * ab, stage + m * n * ab, n * ab,
-                                 hipMemcpyDeviceToDevice, c->cstream));
+        if (packed) {
+          xfer(true, stage, ci << chunk_bits, sv, c->cstream);
+        } else {
+          for (size_t m = 0; m < np; ++m)
+            HIP_TRY(hipMemcpyAsync(psi + (off | blk_off(moves[m].land)) * ab, stage + m * n * ab, n * ab,
+                                   hipMemcpyDeviceToDevice, c->cstream));
+        }
         hipEvent_t cp = c->event();
         if (!cp) return fail(QH_ERR_HIP, "hipEventCreate failed");
         HIP_TRY(hipEventRecord(cp, c->cstream));
@@ -1279,9 +1489,12 @@ int do_exchange(qh_state_s *h, const std::vector<qh::BlockMove> &moves, int base
     }
     HIP_TRY(hipEventRecord(c->t1, c->cstream));
   }
+  rc = check_launch(h);
+  if (rc) return rc;
   c->timing_open = true;
   c->stats.exchanges++;
   c->stats.slabs += K;
+  c->stats.rounds_packed += packed ? (uint64_t)K * nchunks : 0;
   c->stats.bytes_sent += (uint64_t)np * (1ull << (nloc - gbits)) * ab;
   return QH_OK;
 }
@@ -1334,6 +1547,7 @@ int qh_comm_destroy(qh_handle h) {
   if (!h || !h->comm) return QH_OK;
   qh::Comm *c = h->comm;
   (void)hipSetDevice(h->device);
+  if (c->pstream) (void)hipStreamSynchronize(c->pstream);
   if (c->xstream) (void)hipStreamSynchronize(c->xstream);
   if (c->cstream) (void)hipStreamSynchronize(c->cstream);
   if (c->nccl) (void)qh::rccl().CommDestroy(c->nccl);
@@ -1345,6 +1559,7 @@ int qh_comm_destroy(qh_handle h) {
   if (c->h_recv) (void)hipHostFree(c->h_recv);
   if (c->xstream) (void)hipStreamDestroy(c->xstream);
   if (c->cstream) (void)hipStreamDestroy(c->cstream);
+  if (c->pstream) (void)hipStreamDestroy(c->pstream);
   delete c;
   h->comm = nullptr;
   return QH_OK;

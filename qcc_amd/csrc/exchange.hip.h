@@ -30,7 +30,39 @@
 #include <string>
 #include <vector>
 
+#include "kernels_gate.hip.h"
+
 namespace qh {
+
+// PACKED rounds (engine.hip, do_exchange): when the blocks' index bits do not leave long contiguous runs --
+// relayout sweeps move index bits around -- a gather kernel packs the amplitudes of one round into the staging
+// area, peer after peer, and a scatter kernel puts the received ones in place.  Work item i = (peer slot m,
+// amplitude j of the round): index = the round's counter with zeros inserted at the block and slab bits
+// (`ins`), plus the peer's block value and the slab value (`off[m]`).  HBM-bound: n x 16 B read + written.
+constexpr int kMaxXferMoves = 63;
+struct XferGeom {
+  BitIns ins;
+  int np;
+  uint64_t off[kMaxXferMoves];
+};
+template <typename A>
+__global__ __launch_bounds__(256) void k_xpack(const A *__restrict__ psi, A *__restrict__ stage, uint64_t n, uint64_t start, XferGeom g) {
+  const uint64_t total = n * (uint64_t)g.np;
+  const int nb = 63 - __builtin_clzll(n);
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (uint64_t)gridDim.x * 256) {
+    const uint64_t idx = expand_index(start + (i & (n - 1)), g.ins) | g.off[i >> nb];
+    st_amp<true>(stage + i, ld_amp<true>(psi + idx));
+  }
+}
+template <typename A>
+__global__ __launch_bounds__(256) void k_xunpack(A *__restrict__ psi, const A *__restrict__ stage, uint64_t n, uint64_t start, XferGeom g) {
+  const uint64_t total = n * (uint64_t)g.np;
+  const int nb = 63 - __builtin_clzll(n);
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (uint64_t)gridDim.x * 256) {
+    const uint64_t idx = expand_index(start + (i & (n - 1)), g.ins) | g.off[i >> nb];
+    st_amp<true>(psi + idx, ld_amp<true>(stage + i));
+  }
+}
 
 struct RcclApi {
   void *lib = nullptr;
@@ -100,8 +132,9 @@ struct Comm {
   qh_round_fn custom = nullptr;      // host-staged transport (tests / no peer access)
   void *custom_user = nullptr;
   hipStream_t xstream = nullptr;     // the links
-  hipStream_t cstream = nullptr;     // staging -> home copies
-  void *staging = nullptr;           // two halves of (peers x chunk) amplitudes
+  hipStream_t cstream = nullptr;     // staging -> home copies / scatter kernels
+  hipStream_t pstream = nullptr;     // gather kernels of packed rounds
+  void *staging = nullptr;           // two receive halves (+ two send halves, packed rounds) of (peers x chunk) amplitudes
   size_t staging_bytes = 0;
   void *h_send = nullptr, *h_recv = nullptr;   // pinned, custom transport only
   size_t h_bytes = 0;

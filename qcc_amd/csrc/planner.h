@@ -31,6 +31,11 @@ struct GateRec {
   int tgt;            // target bit
   double g[8];        // row-major 2x2, (re,im) pairs
   uint64_t neg_mask = 0;  // all these index bits must be 0 (planner-internal: see propagate_x)
+  // planner-internal, sharded handles only (see Planner::plan): `variant` = the gate touches a shard bit, so what
+  // it does differs from rank to rank; `ghost` = on THIS rank it does nothing (its shard-bit control is 0, or its
+  // rank-dependent phase is 1).  Ghosts stay in the gate list so that every rank plans the same sweeps, tiles and
+  // layouts (an exchange needs the ranks to agree on where every index bit lives); they emit no arithmetic.
+  uint8_t ghost = 0, variant = 0;
 };
 
 // The boundary only ever sees the four matrix entries: classify by
@@ -65,7 +70,8 @@ enum : uint32_t { OP_DENSE_REG = 0, OP_DENSE_LANE = 1, OP_DIAG = 2,
 // per-lane matrix coefficients (H.diag(c)), two complex products per lane.
 enum : uint32_t { OPF_DEFER_C = 1, OPF_USE_C = 2, OPF_REAL = 4,  // REAL: all four entries real
                   OPF_BFLY = 8, OPF_BFLY_SHIFT = 4,                // unit-entry butterfly, variant in bits 4..6
-                  OPF_LANE_DPP = 128, OPF_SWAP_RI = 256 };         // lane butterfly by DPP moves; partner re/im exchanged
+                  OPF_LANE_DPP = 128, OPF_SWAP_RI = 256,           // lane butterfly by DPP moves; partner re/im exchanged
+                  OPF_GHOST = 1024 };   // planner-internal: the op of a ghost gate (counted by the cost model, removed before the plan leaves)
 
 // Gates of the form c*M with every entry of M in {1,-1,i,-i} (h, yroot, v = sqrt-x and
 // their adjoints: ops.py:130-132,152-162) cost additions only once the scalar c is moved
@@ -225,9 +231,9 @@ inline int unit_segments(const SweepPlan &sp, int nloc, uint64_t *masks, int *sh
 class Planner {
  public:
   Planner(int nloc, uint64_t shard, int bw, int max_rb, bool split_lanes = true, int wave_bits = -1,
-          bool allow_relayout = false)
+          bool allow_relayout = false, bool keep_ghosts = false)
       : nloc_(nloc), shard_(shard), amp_bytes_(bw == 128 ? 16 : 8), split_lanes_(split_lanes),
-        relayout_(allow_relayout) {
+        relayout_(allow_relayout), keep_ghosts_(keep_ghosts) {
     rb_cap_ = std::min({max_rb, max_reg_bits(bw), nloc - kLaneBits});
     lane_low_ = bw == 128 ? 3 : 4;   // 128-byte lines: 8 complex128 or 16 complex64 amplitudes
     lane_hi_ = kLaneBits - lane_low_;
@@ -240,16 +246,22 @@ class Planner {
     pending.reserve(queue.size());
     const uint64_t lm = (1ull << nloc_) - 1;
     for (const auto &q : queue) {
-      // resolve shard-index bits now: they are constants on this rank
+      // resolve shard-index bits now: they are constants on this rank.  A gate that does nothing HERE (its
+      // shard-bit control is 0, its rank-dependent phase is 1) is dropped on an unsharded handle and kept as
+      // a ghost on a sharded one: the ranks of a sharded state must plan identical sweeps, tile bits and
+      // relayouts whatever their rank index is (GateRec::ghost).
       const uint64_t hi = q.ctl_mask >> nloc_;
-      if ((shard_ & hi) != hi) { out.noop_gates++; continue; }
       GateRec r = q;
       r.ctl_mask &= lm;
+      r.variant = (hi != 0 || q.tgt >= nloc_) ? 1 : 0;
+      r.ghost = ((shard_ & hi) != hi) ? 1 : 0;
+      if (r.ghost && !keep_ghosts_) { out.noop_gates++; continue; }
       if (r.tgt >= nloc_) {
         // diagonal gate on a shard bit: a scalar factor under the local controls
         const bool set = (shard_ >> (r.tgt - nloc_)) & 1ull;
         const double fr = set ? r.g[6] : r.g[0], fi = set ? r.g[7] : r.g[1];
-        if (is_one(fr, fi)) { out.noop_gates++; continue; }
+        if (is_one(fr, fi)) r.ghost = 1;
+        if (r.ghost && !keep_ghosts_) { out.noop_gates++; continue; }
         // re-express as a one-sided diagonal gate on one of its control bits, or
         // as a global factor (tgt = -1) when it has no local control
         if (r.ctl_mask) {
@@ -261,17 +273,21 @@ class Planner {
           r.tgt = -1;
           r.g[0] = fr; r.g[1] = fi; r.g[6] = fr; r.g[7] = fi;
         }
+        if (r.ghost) { r.g[0] = r.g[6] = 1; r.g[1] = r.g[7] = 0; }   // (never read: a ghost emits nothing)
         r.g[2] = r.g[3] = r.g[4] = r.g[5] = 0;
+        if (r.ghost) out.noop_gates++;
         pending.push_back(r);
-        alg_override_.push_back(gate_alg_bytes(q, nloc_, amp_bytes_));
+        alg_override_.push_back(r.ghost ? 0 : gate_alg_bytes(q, nloc_, amp_bytes_));
         continue;
       }
-      if (is_diag(r.g) && is_one(r.g[0], r.g[1]) && is_one(r.g[6], r.g[7])) { out.noop_gates++; continue; }
+      if (!r.variant && is_diag(r.g) && is_one(r.g[0], r.g[1]) && is_one(r.g[6], r.g[7])) { out.noop_gates++; continue; }
+      if (r.ghost) out.noop_gates++;
       pending.push_back(r);
-      alg_override_.push_back(gate_alg_bytes(r, nloc_, amp_bytes_));
+      alg_override_.push_back(r.ghost ? 0 : gate_alg_bytes(r, nloc_, amp_bytes_));
     }
     std::vector<uint64_t> alg = alg_override_;
     std::vector<uint32_t> weight(pending.size(), 1);
+    for (size_t i = 0; i < pending.size(); ++i) if (pending[i].ghost) weight[i] = 0;
     std::vector<int> first_tile;
     fuse_sleator_weinfurter(&pending, &alg, &weight);
     if (propagate_x_) propagate_x(&pending, &alg, &weight, &out.noop_gates);
@@ -331,6 +347,7 @@ class Planner {
   int lane_low_ = kLaneLow, lane_hi_ = kLaneHi;
   bool split_lanes_;   // allow lane bits 3..5 to sit on arbitrary index bits (8 free tile bits)
   bool relayout_;      // sweeps may store into the second buffer with the tile bits moved to the low positions
+  bool keep_ghosts_;   // sharded handle: gates that do nothing on this rank stay in the list (GateRec::ghost)
   bool butterflies_ = env_flag("QH_BFLY", true);        // unit-entry butterfly ops (emit_ops_with)
   size_t dense_weight_ = env_int("QH_PLAN_DENSE_W", 1);  // score of a dense gate when choosing tile bits (diagonal = 1)
   // wave bits per tile (see plan_best): QH_WAVE_BITS pins it
@@ -387,7 +404,7 @@ class Planner {
     };
     for (size_t i = 0; i < pending->size(); ++i) {
       GateRec r = (*pending)[i];
-      if (r.tgt >= 0 && r.ctl_mask == 0 && r.neg_mask == 0 && is_x(r.g)) {
+      if (r.tgt >= 0 && r.ctl_mask == 0 && r.neg_mask == 0 && is_x(r.g) && !r.variant) {   // (an X under a shard-bit control is a gate like any other)
         flip ^= 1ull << r.tgt;
         carry_alg += (*alg)[i];
         carry_w += (*weight)[i];
@@ -403,7 +420,8 @@ class Planner {
       // A diagonal gate under zero-controls expands into 2^k phase terms with inverse factors:
       // with a zero on its diagonal (projectors) or past three zero-controls, the flips of its
       // control bits are executed here instead.
-      const bool singular = (r.g[0] == 0.0 && r.g[1] == 0.0) || (r.g[6] == 0.0 && r.g[7] == 0.0);
+      // (a diagonal gate that touches a shard bit has rank-dependent entries: every rank takes the cautious branch)
+      const bool singular = r.variant || (r.g[0] == 0.0 && r.g[1] == 0.0) || (r.g[6] == 0.0 && r.g[7] == 0.0);
       if (plan_diag(r.g, r.tgt) && c && (singular || popc((r.neg_mask ^ c) & (r.ctl_mask | r.neg_mask)) > 3)) {
         for (uint64_t t = c; t; t &= t - 1) {
           const int b = __builtin_ctzll(t);
@@ -464,7 +482,8 @@ class Planner {
       if (i + 4 < q.size()) {
         const GateRec &g1 = q[i], &g2 = q[i + 1], &g3 = q[i + 2], &g4 = q[i + 3], &g5 = q[i + 4];
         const int t = g1.tgt, b = g2.tgt;
-        if (t >= 0 && b >= 0 && b != t && g3.tgt == t && g5.tgt == t && g4.tgt == b && is_x(g2.g) &&
+        const bool any_variant = g1.variant || g2.variant || g3.variant || g4.variant || g5.variant;
+        if (!any_variant && t >= 0 && b >= 0 && b != t && g3.tgt == t && g5.tgt == t && g4.tgt == b && is_x(g2.g) &&
             is_x(g4.g) && g2.ctl_mask == g4.ctl_mask && g1.ctl_mask == g2.ctl_mask &&
             g3.ctl_mask == g5.ctl_mask && !((g1.ctl_mask >> b) & 1ull) && ((g3.ctl_mask >> b) & 1ull)) {
           const uint64_t common = g3.ctl_mask & ~(1ull << b);
@@ -853,12 +872,16 @@ class Planner {
   // reference gates meet in few DIAG ops and merge into tables.
   void emit_ops(const std::vector<const GateRec *> &taken, SweepPlan *sp) {
     emit_ops_with(taken, sp, LaneChoice{});
-    if (!lane_valu_) return;
-    LaneChoice ch = choose_lane_paths(*sp);
-    if (lane_valu_ == 2) ch.dpp01 = ch.dpp23 = ch.lswap = ch.real01 = ch.real23 = 1 << 20;
-    if (ch.dpp01 + ch.dpp23 + ch.lswap + ch.real01 + ch.real23 == 0) return;
-    sp->ops.clear(); sp->groups.clear(); sp->oterms.clear(); sp->tables.clear(); sp->ltabs.clear();
-    emit_ops_with(taken, sp, ch);
+    if (lane_valu_) {
+      LaneChoice ch = choose_lane_paths(*sp);     // (ghost ops count: the choice must not depend on the rank)
+      if (lane_valu_ == 2) ch.dpp01 = ch.dpp23 = ch.lswap = ch.real01 = ch.real23 = 1 << 20;
+      if (ch.dpp01 + ch.dpp23 + ch.lswap + ch.real01 + ch.real23 != 0) {
+        sp->ops.clear(); sp->groups.clear(); sp->oterms.clear(); sp->tables.clear(); sp->ltabs.clear();
+        emit_ops_with(taken, sp, ch);
+      }
+    }
+    sp->ops.erase(std::remove_if(sp->ops.begin(), sp->ops.end(), [](const SweepOp &o) { return (o.flags & OPF_GHOST) != 0; }),
+                  sp->ops.end());
   }
 
   void emit_ops_with(const std::vector<const GateRec *> &taken, SweepPlan *sp, LaneChoice ch) {
@@ -873,7 +896,7 @@ class Planner {
       std::vector<int> cand;
       for (size_t i = 0; i < taken.size(); ++i) {
         const GateRec *r = taken[i];
-        if (plan_diag(r->g, r->tgt) || (r->ctl_mask & ~sp->fixed_ones) || r->neg_mask) continue;
+        if (plan_diag(r->g, r->tgt) || (r->ctl_mask & ~sp->fixed_ones) || r->neg_mask || r->variant) continue;
         last = (int)i;
         if (butterflies_ && butterfly_variant(r->g) >= 0) cand.push_back((int)i);
       }
@@ -994,6 +1017,7 @@ class Planner {
     for (size_t gi = 0; gi < taken.size(); ++gi) {
       const GateRec *r = taken[gi];
       const bool diag = plan_diag(r->g, r->tgt);
+      if (diag && r->ghost) continue;           // (no phase here; diagonal gates never move the layout)
       if (!diag) {
         // a target that lives in the wave id comes into a register bit first: the phases
         // waiting for this gate are then in-tile factors instead of one group per partner bit
@@ -1034,6 +1058,14 @@ class Planner {
         }
         if (li >= 0) { op.kind = OP_DENSE_LANE; op.tb = (uint32_t)li; }
         else { op.kind = OP_DENSE_REG; op.tb = reg_index(geom, r->tgt); }
+        if (r->ghost) {
+          // the layout exchanges above happened as on the ranks where the gate is live, and the cost model
+          // (choose_lane_paths) sees an op of the same kind; emit_ops() removes it
+          op.flags = OPF_GHOST;
+          memset(op.g, 0, sizeof op.g);
+          sp->ops.push_back(op);
+          continue;
+        }
         if (op.g[1] == 0.0 && op.g[3] == 0.0 && op.g[5] == 0.0 && op.g[7] == 0.0) op.flags |= OPF_REAL;
         if (bv >= 0) {
           op.flags = OPF_BFLY | ((uint32_t)bv << OPF_BFLY_SHIFT);
@@ -1391,12 +1423,12 @@ inline bool plan_has_far_tile(const PlanResult &pr) {
 }
 
 inline PlanResult plan_best(const std::vector<GateRec> &queue, int nloc, uint64_t shard, int bw, int max_rb,
-                            bool split_lanes, bool allow_relayout = false) {
-  if (getenv("QH_WAVE_BITS")) return Planner(nloc, shard, bw, max_rb, split_lanes, -1, allow_relayout).plan(queue);
+                            bool split_lanes, bool allow_relayout = false, bool keep_ghosts = false) {
+  if (getenv("QH_WAVE_BITS")) return Planner(nloc, shard, bw, max_rb, split_lanes, -1, allow_relayout, keep_ghosts).plan(queue);
   PlanResult best;
   bool have = false, best_far = false;
   for (int wb : {1, 2, 0}) {
-    PlanResult pr = Planner(nloc, shard, bw, max_rb, split_lanes, wb, allow_relayout).plan(queue);
+    PlanResult pr = Planner(nloc, shard, bw, max_rb, split_lanes, wb, allow_relayout, keep_ghosts).plan(queue);
     const bool far = plan_has_far_tile(pr);
     if (!have || (best_far && !far) || (best_far == far && pr.sweeps.size() < best.sweeps.size())) {
       best = std::move(pr);
@@ -1409,9 +1441,10 @@ inline PlanResult plan_best(const std::vector<GateRec> &queue, int nloc, uint64_
 }
 
 inline std::string plan_to_json(const std::vector<GateRec> &queue, int nloc, uint64_t shard, int bw = 128,
-                                int max_rb = kMaxRegBits, bool split_lanes = true, bool allow_relayout = false) {
+                                int max_rb = kMaxRegBits, bool split_lanes = true, bool allow_relayout = false,
+                                bool keep_ghosts = false) {
   if (nloc < kLaneBits + 2) return "{\"sweeps\":[],\"note\":\"state too small for sweeps\"}";
-  PlanResult pr = plan_best(queue, nloc, shard, bw, max_rb, split_lanes, allow_relayout);
+  PlanResult pr = plan_best(queue, nloc, shard, bw, max_rb, split_lanes, allow_relayout, keep_ghosts);
   std::string s = "{\"noop_gates\":" + std::to_string(pr.noop_gates) + ",\"sweeps\":[";
   char buf[384];
   for (size_t i = 0; i < pr.sweeps.size(); ++i) {

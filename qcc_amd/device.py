@@ -105,6 +105,12 @@ class DeviceState:
   def set_fusion(self, level):
     native.check(self.lib.qh_set_fusion(self.h, int(level)))
 
+  def set_relayout(self, on):
+    """Relayout sweeps on/off (qh_set_relayout); returns the resulting mode."""
+    actual = ctypes.c_int(0)
+    native.check(self.lib.qh_set_relayout(self.h, 1 if on else 0, ctypes.byref(actual)))
+    return bool(actual.value)
+
   def set_shard(self, nbits_global, shard_index):
     native.check(self.lib.qh_set_shard(self.h, int(nbits_global), int(shard_index)))
     self.nbits_global = int(nbits_global)
@@ -183,16 +189,12 @@ class DeviceState:
 
   def run_stream(self, ops, gates8):
     """ops int32[G,2] (ctl or NO_CTL, tgt), gates8 float64[G,8] -- reference qubit numbers."""
-    ops = np.ascontiguousarray(ops, dtype=np.int32)
-    gates8 = np.ascontiguousarray(gates8, dtype=np.float64)
-    a1, ac, h = self.lib.qh_apply1, self.lib.qh_applyc, self.h
-    base = gates8.ctypes.data
-    for k in range(len(ops)):
-      gp = ctypes.cast(base + 64 * k, _dp)
-      c, t = int(ops[k, 0]), int(ops[k, 1])
-      rc = a1(h, t, gp) if c == NO_CTL else ac(h, c, t, gp)
-      if rc:
-        native.check(rc)
+    ops = np.ascontiguousarray(ops, dtype=np.int32).reshape(-1, 2)
+    gates8 = np.ascontiguousarray(gates8, dtype=np.float64).reshape(-1, 8)
+    assert len(ops) == len(gates8)
+    # one FFI call for the stream: exactly len(ops) qh_apply1 / qh_applyc calls inside (include/qcc_hip.h)
+    native.check(self.lib.qh_apply_stream(self.h, len(ops), ops.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                                          gates8.ctypes.data_as(_dp)))
 
   def flush(self):
     native.check(self.lib.qh_flush(self.h))

@@ -48,6 +48,7 @@ except Exception:  # pylint: disable=broad-except
     _flags = None
 
 _SNAPSHOT_LIMIT_BITS = 31  # above this a full host snapshot is refused (>= 32 GiB)
+_MEASURE_SNAPSHOT_BITS = 26  # measure_bit returns the real State up to here (1 GiB), a lazy handle above
 _ALIAS_LIMIT_BITS = 26     # alias_psi: registers up to this size live in host-mapped memory
 
 
@@ -73,21 +74,39 @@ def _sqrt2x2(u):
     return (u + s * np.eye(2)) / t
 
 
-class _LazyPsi:
-    """What measure_bit() hands back as the state (circuit.py:287-297 returns (prob, psi)): nothing is
-    copied from the device until the caller actually looks at it -- most callers only want the
-    probability.  Like the reference's in-place State it shows the circuit's state at the time it is
-    READ (src/lib/xgates.cc:37-38 mutates the one buffer every holder of `psi` sees)."""
+class _LazyPsi(np.lib.mixins.NDArrayOperatorsMixin):
+    """What measure_bit() hands back as the state of a LARGE register (circuit.py:287-297 returns
+    (prob, psi)): most callers only want the probability, so nothing is copied from the device until the
+    caller actually looks.  The first look takes a snapshot (a real, read-only State) and every later
+    look sees that same snapshot -- the value does not drift when more gates follow.  It is a snapshot of
+    the state AT THE TIME OF THE FIRST LOOK; registers of <= 26 qubits get the real State at measurement
+    time instead (see measure_bit).  Arithmetic, comparisons and ufuncs work as on the State."""
 
     def __init__(self, owner):
         self._owner = owner
+        self._snap = None
 
     def _get(self):
-        return self._owner.psi
+        if self._snap is None:
+            self._snap = self._owner.psi
+            self._owner = None
+        return self._snap
 
     def __array__(self, dtype=None, copy=None):
         a = np.asarray(self._get())
         return a.astype(dtype) if dtype is not None else a
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+        inputs = tuple(x._get() if isinstance(x, _LazyPsi) else x for x in inputs)
+        if 'out' in kwargs:
+            kwargs['out'] = tuple(x._get() if isinstance(x, _LazyPsi) else x for x in kwargs['out'])
+        return getattr(ufunc, method)(*inputs, **kwargs)
+
+    def __matmul__(self, other):
+        return self._get() @ (other._get() if isinstance(other, _LazyPsi) else other)
+
+    def __rmatmul__(self, other):
+        return other @ self._get()
 
     def __getattr__(self, name):
         return getattr(self._get(), name)
@@ -100,6 +119,9 @@ class _LazyPsi:
 
     def __iter__(self):
         return iter(self._get())
+
+    def __repr__(self):
+        return repr(self._get())
 
 
 class qc:
@@ -446,6 +468,10 @@ class qc:
             dev.project_bit(bit, 1 if tostate else 0)
             dev.scale(1.0 / math.sqrt(prob))
             self._gate_done()
+        # circuit.py:291-297 returns the State itself: small registers (and aliased ones, whose psi is the
+        # device's own memory) get exactly that, isinstance(psi, State) included; larger ones a lazy handle
+        if self._nbits <= _MEASURE_SNAPSHOT_BITS or self._aliased():
+            return prob, self.psi
         return prob, _LazyPsi(self)
 
     def pauli_expectation(self, idx):

@@ -59,6 +59,8 @@ SIGNATURES = {
     'qh_applyc': (_i32, [_vp, _i32, _i32, _dp]),
     'qh_apply_bits': (_i32, [_vp, _u64, _i32, _dp]),
     'qh_set_fusion': (_i32, [_vp, _i32]),
+    'qh_set_relayout': (_i32, [_vp, _i32, ctypes.POINTER(_i32)]),
+    'qh_apply_stream': (_i32, [_vp, _u64, ctypes.POINTER(ctypes.c_int32), _dp]),
     'qh_flush': (_i32, [_vp]),
     'qh_sync': (_i32, [_vp]),
     'qh_pending_gates': (_i32, [_vp, ctypes.POINTER(_u64)]),
@@ -88,7 +90,7 @@ SIGNATURES = {
 
 class QhXStats(ctypes.Structure):
   _fields_ = [('exchanges', _u64), ('rounds', _u64), ('bytes_sent', _u64), ('slabs', _u64),
-              ('sweeps_overlapped', _u64), ('span_ms', ctypes.c_double)]
+              ('sweeps_overlapped', _u64), ('span_ms', ctypes.c_double), ('rounds_packed', _u64)]
 
   def as_dict(self):
     return {k: getattr(self, k) for k, _ in self._fields_}

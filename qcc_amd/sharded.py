@@ -35,10 +35,15 @@ torch.distributed (control plane).  `self.exchange_path` says which path is live
   'torch-p2p'   torch.distributed.batch_isend_irecv on torch views of the shard -- the CPU test
                 double (gloo, `engine_factory`), or QCC_EXCHANGE=torch.
 
-The local engine is qcc_amd.device.DeviceState attached to a torch CUDA tensor
-(so torch.distributed can address the same HBM).  Tests substitute a CPU engine
-and the gloo backend through `engine_factory` to exercise exactly this routing /
-bit-map code with world_size 2 and 4.
+The local engine is a qcc_amd.device.DeviceState that OWNS its shard (qh_create + qh_set_shard): it
+may then re-lay the shard out between its two buffers like a single-GPU handle does (relayout sweeps,
+planner.h), and the exchange follows the index bits wherever they are (packed rounds).  Every rank
+submits EVERY gate to its engine -- also the ones whose shard-bit control is 0 on this rank: the
+planner keeps those as ghosts, so that all ranks plan the same sweeps, tiles, slabs and layouts (an
+exchange needs them to agree; engine.hip verify_geometry checks it).  Only the torch-p2p double
+(QCC_EXCHANGE=torch, or CPU engines through `engine_factory`) works on a torch allocation and resolves
+shard-bit controls here.  Tests substitute a CPU engine and the gloo backend through `engine_factory`
+to exercise exactly this routing / bit-map code with world_size 2 and 4.
 """
 import math
 import os
@@ -52,8 +57,9 @@ def _is_diag(g4):
   return g4[1] == 0 and g4[2] == 0
 
 
-def _hip_engine_factory(nloc, local_rank, fusion, bit_width=128):
-  """(engine, flat real-valued torch view of the shard) on cuda:local_rank."""
+def _hip_engine_factory(nloc, local_rank, fusion, bit_width=128, torch_memory=False):
+  """(engine, flat real-valued torch view of the shard or None) on cuda:local_rank.  The engine owns its
+  shard unless `torch_memory` (the torch-p2p exchange needs torch views of it)."""
   import torch
   from qcc_amd import device
   if not torch.cuda.is_available():
@@ -61,6 +67,8 @@ def _hip_engine_factory(nloc, local_rank, fusion, bit_width=128):
                        'runtimes are mapped (see qcc_amd.native._preload_torch_runtime): import torch first or '
                        'launch through torchrun / set QCC_PRELOAD_TORCH=1')
   torch.cuda.set_device(local_rank)
+  if not torch_memory:
+    return device.DeviceState(nloc, bit_width, device=local_rank, fusion=fusion), None
   buf = torch.zeros(2 << nloc, dtype=torch.float64 if bit_width == 128 else torch.float32, device=f'cuda:{local_rank}')
   eng = device.DeviceState(nloc, bit_width, device=local_rank, fusion=fusion, device_ptr=buf.data_ptr())
   return eng, buf
@@ -99,11 +107,15 @@ class ShardedState:
     self.bit_width = int(bit_width)
     self.amp_bytes = 16 if self.bit_width == 128 else 8
     self.cdtype = np.complex128 if self.bit_width == 128 else np.complex64
-    factory = engine_factory or (lambda nloc: _hip_engine_factory(nloc, local_rank, fusion, self.bit_width))
+    self._local_rank = local_rank
+    want_torch_p2p = os.environ.get('QCC_EXCHANGE') == 'torch'
+    factory = engine_factory or (lambda nloc: _hip_engine_factory(nloc, local_rank, fusion, self.bit_width, want_torch_p2p))
     self.eng, self.buf = factory(self.nloc)
     self._hip = hasattr(self.eng, 'lib')          # the real engine: knows its shard, builds states on the device
     if self._hip:
       self.eng.set_shard(self.nbits, self.rank)
+    # the real engine resolves shard-bit controls itself and must see every gate on every rank (ghosts, planner.h)
+    self._pass_all = self._hip and not want_torch_p2p
     # logical bit b (0 = least significant; qubit q is bit nbits-1-q) -> physical bit
     self.perm = list(range(self.nbits))
     self.chunk = min(int(chunk_amps), 1 << (self.nloc - 1))
@@ -122,6 +134,10 @@ class ShardedState:
     self._native_chunk = int(os.environ.get('QCC_EXCHANGE_CHUNK_AMPS', '0')) or self.chunk
     if self.world > 1 or os.environ.get('QCC_EXCHANGE') == 'native':
       self._init_native_exchange()
+    if self._hip and self.buf is None and not self._native and self.world > 1:
+      raise RuntimeError(f'the engine-native exchange could not be set up ({self.exchange_path}); '
+                         'QCC_EXCHANGE=torch selects the torch.distributed double explicitly')
+    self.relayout = self._agree_on_relayout()
 
   def _init_native_exchange(self):
     """Engine-native transport when the engine is the HIP one (see the module docstring)."""
@@ -158,6 +174,21 @@ class ShardedState:
   def _native(self):
     return self.exchange_path in ('rccl', 'host-staged')
 
+  def _agree_on_relayout(self):
+    """Relayout sweeps need a second buffer of the shard's size on EVERY rank (the ranks must hold the same
+    layout when they exchange): each rank tries, and one that cannot makes all of them give it back."""
+    if not self._hip or self.buf is not None or not hasattr(self.eng, 'set_relayout'):
+      return False
+    if self.world == 1:
+      return None                            # the engine decides at its first flush, like any single-GPU handle
+    mine = 1 if self.eng.set_relayout(True) else 0
+    t = self.torch.tensor([mine], dtype=self.torch.int32, device=self._red_device())
+    self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+    if int(t.item()) == 0:
+      self.eng.set_relayout(False)
+      return False
+    return True
+
   # ------------------------------------------------------------------ helpers
   def _phys_mask(self, logical_mask):
     m, b = 0, 0
@@ -182,8 +213,8 @@ class ShardedState:
     """|index> (logical); only the owning rank gets the 1."""
     phys = self.logical_to_phys(int(index))
     if self._hip:
-      self.eng.init_basis(phys)             # (the engine's own bit map is the identity: physical == its logical)
-      return
+      self.eng.init_basis(phys)             # (this layer's physical bits are the engine's logical ones: it keeps its own map of
+      return                                #  where its relayout sweeps have moved the local bits)
     self.eng.sync()
     self.buf.zero_()
     if self.buf.is_cuda:
@@ -207,6 +238,9 @@ class ShardedState:
       self._seq += 1
       self._last_use[pt] = self._seq
     pm = self._phys_mask(ctl_mask)
+    if self._pass_all:
+      self.eng.apply_bits(pm, pt, g4)          # shard-bit controls / diagonal shard targets: resolved by the engine
+      return
     hi = pm >> self.nloc
     if (self.rank & hi) != hi:
       return                                   # a control lives in the rank index and is 0 here
@@ -248,6 +282,7 @@ class ShardedState:
     raw = self.eng.apply_bits_raw
     perm = self.perm
     gc = None
+    pass_all = self._pass_all
     for k in range(len(cq)):
       tb = tbits[k]
       pt = perm[tb]
@@ -257,7 +292,7 @@ class ShardedState:
           self._exchange(pt, evict)
           perm = self.perm
           pt = perm[tb]
-        else:                                  # diagonal on a shard bit: general path
+        elif not pass_all:                     # diagonal on a shard bit: general path
           if gc is None:
             gc = g8.view(np.complex128).reshape(-1, 4)
           cmask = 0 if cq[k] == NO_CTL else 1 << (n - 1 - cq[k])
@@ -276,7 +311,7 @@ class ShardedState:
         if c == tb:
           raise ValueError(f'control == target (qubit {cq[k]})')
         pc = perm[c]
-        if pc >= nloc:
+        if pc >= nloc and not pass_all:
           if not (rank >> (pc - nloc)) & 1:
             continue
           cm = 0
@@ -469,7 +504,9 @@ class ShardedState:
 
   def _red_device(self):
     """Device for the tiny reduction tensors: the shard's device under RCCL, host under gloo."""
-    return 'cpu' if self.dist.get_backend() == 'gloo' else self.buf.device
+    if self.dist.get_backend() == 'gloo':
+      return 'cpu'
+    return self.buf.device if self.buf is not None else f'cuda:{self._local_rank}'
 
   def norm2_global(self):
     if self.exchange_path == 'rccl':          # 8 bytes over the engine's own communicator
@@ -482,6 +519,14 @@ class ShardedState:
     """(logical index, probability) of the likeliest basis state."""
     li, p = self.eng.argmax()
     phys = (self.rank << self.nloc) | (li & ((1 << self.nloc) - 1))   # (an engine that knows its shard reports global bits)
+    if self.exchange_path == 'rccl':
+      # one communicator for everything the data path does: the engine's (ONE all-reduce of 2 x world doubles:
+      # every rank fills its own slots; indices < 2^53 are exact in a double)
+      v = np.zeros(2 * self.world)
+      v[2 * self.rank], v[2 * self.rank + 1] = p, float(phys)
+      v = self.eng.allreduce_sum(v)
+      best = max(range(self.world), key=lambda r: (float(v[2 * r]), -r))
+      return self.phys_to_logical(int(v[2 * best + 1])), float(v[2 * best])
     t = self.torch.tensor([p, float(self.rank)], dtype=self.torch.float64, device=self._red_device())
     allp = [self.torch.zeros_like(t) for _ in range(self.world)]
     self.dist.all_gather(allp, t)
@@ -504,6 +549,18 @@ class ShardedState:
     """Whole state in LOGICAL order on every rank (tests / small n only)."""
     torch = self.torch
     self.eng.sync()
+    if self.buf is None:                    # the engine owns the shard: download it (canonical order of its local bits)
+      mine = torch.from_numpy(self.eng.download().view(np.float64 if self.bit_width == 128 else np.float32))
+      if self.dist.get_backend() != 'gloo':
+        mine = mine.to(self._red_device())
+      parts = [torch.zeros_like(mine) for _ in range(self.world)]
+      self.dist.all_gather(parts, mine)
+      phys = np.concatenate([p_.cpu().numpy().view(self.cdtype) for p_ in parts])
+      idx = np.arange(1 << self.nbits, dtype=np.uint64)
+      pidx = np.zeros_like(idx)
+      for b in range(self.nbits):
+        pidx |= ((idx >> np.uint64(b)) & np.uint64(1)) << np.uint64(self.perm[b])
+      return phys[pidx]
     if self.buf.is_cuda:
       torch.cuda.synchronize()
     mine = self.buf.detach().to('cpu') if self.buf.is_cuda else self.buf
@@ -551,7 +608,7 @@ class ShardedState:
   def close(self):
     self.eng.sync()
     self.eng.close()
-    if getattr(self.buf, 'is_cuda', False):
+    if self.buf is not None and getattr(self.buf, 'is_cuda', False):
       # hand the shard (up to 128 GiB) back to the driver: torch's caching allocator would keep it,
       # and the engine's own hipMalloc calls in this process do not see torch's cache
       self.buf = self._staging = None
@@ -581,6 +638,8 @@ class ShardedDevice:
 
   def _all_sum(self, values):
     st = self.st
+    if st.exchange_path == 'rccl':           # the engine's communicator (one communicator on the data path)
+      return [float(v) for v in st.eng.allreduce_sum([float(v) for v in values])]
     t = st.torch.tensor([float(v) for v in values], dtype=st.torch.float64, device=st._red_device())
     st.dist.all_reduce(t)
     return [float(v) for v in t.tolist()]

@@ -42,9 +42,15 @@ def _self_round(peers, send, recv):
 
 
 @pytest.mark.parametrize('transport', ['rccl', 'host'])
+@pytest.mark.parametrize('pack', ['auto', 'packed', 'direct'])
 @pytest.mark.parametrize('n,bit,chunk,bw', [(22, 21, 1 << 14, 128), (22, 13, 1 << 10, 128), (20, 19, 0, 64),
                                             (24, 9, 1 << 16, 128)])
-def test_loopback_exchange_equals_x_gate(oracle, transport, n, bit, chunk, bw):
+def test_loopback_exchange_equals_x_gate(oracle, monkeypatch, transport, pack, n, bit, chunk, bw):
+  """`bit` is a LOGICAL bit: the handle owns its memory and keeps re-laying the state out while the communicator
+  exists (one rank: nobody to disagree with), so the blocks' bit may sit anywhere when the exchange starts --
+  rounds are then packed by a gather kernel; 'packed' / 'direct' force either way of moving a round."""
+  if pack != 'auto':
+    monkeypatch.setenv('QH_EXCHANGE_PACK', '1' if pack == 'packed' else '0')
   a_ops, a_g = _circuit(n, 100 + bit, 40)
   b_ops, b_g = _circuit(n, 200 + bit, 40)
   q_ops, q_g = workloads.qft_stream(range(n)).arrays()
@@ -56,8 +62,8 @@ def test_loopback_exchange_equals_x_gate(oracle, transport, n, bit, chunk, bw):
   with device.DeviceState(n, bw, fusion=native.QH_FUSE_SWEEP) as st:
     st.init_basis(5)
     st.run_stream(a_ops, a_g)
-    st.flush()                         # (an owning handle may re-lay the state out here: the communicator
-    if transport == 'rccl':            #  attaches to a canonical layout again)
+    st.flush()                         # (the owning handle has re-laid the state out by now)
+    if transport == 'rccl':
       st.comm_init(1, 0, device.DeviceState.comm_unique_id())
     else:
       st.comm_init_custom(1, 0, _self_round)
@@ -75,8 +81,66 @@ def test_loopback_exchange_equals_x_gate(oracle, transport, n, bit, chunk, bw):
   assert abs(n2 - 1) < (1e-11 if bw == 128 else 1e-4)
   assert xs['exchanges'] == 3 and xs['rounds'] >= 3 and xs['bytes_sent'] == 3 * (1 << n) * (16 if bw == 128 else 8)
   assert xs['slabs'] >= 3 and xs['span_ms'] > 0
+  if pack == 'packed':
+    assert xs['rounds_packed'] == xs['rounds']
+  if pack == 'direct':
+    assert xs['rounds_packed'] == 0
   if n >= 22:
     assert xs['sweeps_overlapped'] >= 1   # at least one neighbouring sweep was cut into slabs
+
+
+@pytest.mark.parametrize('relayout', ['1', '0'])
+def test_loopback_exchange_at_shard_size(monkeypatch, relayout, capsys):
+  """Config 5's exchange leg at FULL shard size on one GPU (VERDICT r2, next #1a): a 2^33-amplitude handle with a
+  1-rank RCCL communicator sends the two 64-GiB halves selected by its top logical bit to itself -- default
+  chunk, 8 slabs, 2 x 256 rounds of grouped ncclSend/ncclRecv, the staging halves, the landing copies (or, with
+  relayout sweeps, the gather / scatter kernels) and the event chain between the four streams -- with a queued
+  33-qubit sweep in front of it (cut into slabs) and one behind it (started slab by slab).  The data movement is
+  an X gate on that bit; the circuit around it is a QFT, so the exact product-state oracle checks the result."""
+  from tests.product_oracle import ProductState
+  monkeypatch.setenv('QH_RELAYOUT', relayout)
+  n, bit = 33, 32
+  try:
+    st = device.DeviceState(n, 128, fusion=native.QH_FUSE_SWEEP)
+  except native.QhError as e:
+    if e.code == native.QH_ERR_NOMEM:
+      pytest.skip(f'cannot allocate 2^{n} amplitudes on this box: {e}')
+    raise
+  ops, g8 = workloads.qft_stream(range(n)).arrays()
+  cut = int(np.flatnonzero((ops[:, 0] == NO_CTL) & (ops[:, 1] == n - 1 - 21))[0])   # the H on logical bit 21: two sweeps' worth before it
+  x = 0x12CB9A5E3 & ((1 << n) - 1)
+  x_ops, x_g = _x_on_bit(n, bit)
+  ps = ProductState(n, x)
+  ps.run(ops, g8, 0, cut)
+  ps.run(x_ops, x_g)
+  ps.run(ops, g8, cut, len(ops))
+  with st:
+    st.comm_init(1, 0, device.DeviceState.comm_unique_id())
+    st.init_basis(x)
+    st.run_stream(ops[:cut], g8[:cut])     # queued: the exchange plans them and cuts the last sweep into slabs
+    st.exchange_loopback(bit, 0)           # default chunk (2^22 amplitudes per peer and round)
+    st.run_stream(ops[cut:], g8[cut:])     # the first sweep of these starts slab by slab as the slabs land
+    st.flush()
+    st.sync()
+    xs = st.exchange_stats()
+    s = st.stats()
+    n2 = st.norm2()
+    rng = np.random.default_rng(33)
+    idx = np.concatenate([np.arange(o, o + 512, dtype=np.uint64) for o in
+                          [0, (1 << n) - 512] + [int(v) for v in rng.integers(0, (1 << n) - 512, size=24)]])
+    amp = np.array([st.amplitude(int(i)) for i in idx[::16]])      # by logical index: no re-layout pass
+    with capsys.disabled():
+      print(f'\n[exchange @2^33, QH_RELAYOUT={relayout}] span_ms={xs["span_ms"]:.1f} rounds={xs["rounds"]} packed={xs["rounds_packed"]} '
+            f'slabs={xs["slabs"]} sweeps_overlapped={xs["sweeps_overlapped"]} sweeps={s["sweeps"]} '
+            f'GB/s(one way)={xs["bytes_sent"] / max(xs["span_ms"], 1e-9) / 1e6:.0f}')
+  want = ps.amplitudes(idx[::16])
+  assert np.max(np.abs(want)) > 1e-6
+  assert np.max(np.abs(amp - want)) < 1e-10
+  assert abs(n2 - 1) < 1e-9
+  assert xs['exchanges'] == 1 and xs['bytes_sent'] == (1 << n) * 16 and xs['slabs'] == 8
+  assert xs['rounds'] == (1 << (n - 1)) >> 22            # half the shard per move, 2^22 amplitudes per round
+  assert xs['sweeps_overlapped'] == 2                    # the sweep before and the sweep after ran slab by slab
+  assert (xs['rounds_packed'] > 0) == (relayout == '1')
 
 
 def test_exchange_needs_a_communicator():

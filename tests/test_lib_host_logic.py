@@ -144,6 +144,33 @@ def test_measure_bit_matches_projector_formulation():
   assert bits == hb and abs(p - hp) < 1e-15
 
 
+def test_measure_bit_returns_a_real_state_snapshot():
+  """circuit.py:291-297 hands back (prob, State): dispatch on isinstance(.., State) and arithmetic must work,
+  and the value must be the state at measurement time, not at read time."""
+  qc = circuit.qc('m')
+  qc.reg(3, 0)
+  qc.h(0); qc.cx(0, 1)
+  p, psi = qc.measure_bit(0, 1, collapse=True)
+  assert isinstance(psi, state.State) and abs(p - 0.5) < 1e-14
+  kept = np.array(psi)
+  qc.h(2)                                         # more gates: the snapshot must not follow them
+  assert np.array_equal(np.array(psi), kept)
+  assert abs(np.vdot(psi, psi) - 1) < 1e-14 and np.allclose((psi * 2)[6], 2 * kept[6])
+  # large registers get the lazy handle: same protocol, snapshot on first look
+  old = circuit._MEASURE_SNAPSHOT_BITS
+  circuit._MEASURE_SNAPSHOT_BITS = 2
+  try:
+    p2, lazy = qc.measure_bit(1, 1, collapse=False)
+    assert isinstance(lazy, circuit._LazyPsi) and abs(p2 - 1.0) < 1e-14
+    first = np.array(lazy)                        # first look: snapshot
+    qc.x(2)
+    assert np.array_equal(np.array(lazy), first)
+    assert np.allclose(lazy * 2, 2 * first) and np.allclose(2 * lazy, 2 * first) and np.allclose(np.abs(lazy), np.abs(first))
+    assert abs((lazy.conj() @ lazy) - 1) < 1e-13 and lazy.nbits == 3 and (lazy == first).all()
+  finally:
+    circuit._MEASURE_SNAPSHOT_BITS = old
+
+
 def test_ir_inverse_control_by_and_run():
   main = circuit.qc('main')
   main.reg(4, 0b0110)

@@ -168,3 +168,62 @@ def test_qft_phase_ladders_become_factor_trees(oracle, monkeypatch, env, bw):
     got = psi.copy()
     plan_interp.run_plan(got, sweeps, n, 0)
     assert float(np.max(np.abs(got - want))) < 1e-11
+
+
+GEOMETRY_KEYS = ('rb', 'regpos', 'regpos_store', 'lanehi', 'nwave', 'wavepos', 'fixed_ones', 'ntiles', 'lane_low', 'relayout',
+                 'dest_pos', 'lanehi_store', 'wavepos_store', 'reg_dest', 'wave_dest', 'unit_runs', 'final_pos')
+
+
+def _shard_variant_stream(rng, n, ngates, gshard):
+  """Random circuit with plenty of RANK-DEPENDENT gates: dense gates under shard-bit controls (dropped on the
+  ranks whose bit is 0), X gates under shard-bit controls, diagonal gates whose target is a shard bit."""
+  base = _stream(rng, n, ngates, gshard)
+  out = []
+  for ctl, t, g in base:
+    r = rng.random()
+    if r < 0.25 and t >= gshard:                      # add a shard-bit control
+      c = int(rng.integers(gshard))
+      ctl = [c] + [q for q in ctl if q != c]
+    elif r < 0.35 and t >= gshard:                    # X / H under ONLY a shard-bit control
+      g = np.asarray(gates.pauli_x() if rng.random() < 0.5 else gates.hadamard(), dtype=np.complex128).reshape(4)
+      ctl = [int(rng.integers(gshard))]
+    elif r < 0.45:                                    # diagonal gate ON a shard bit, maybe under a local control
+      g = np.asarray(gates.u1(float(rng.uniform(0.1, 3))) if rng.random() < 0.7 else gates.pauli_z(), dtype=np.complex128).reshape(4)
+      t = int(rng.integers(gshard))
+      ctl = [int(rng.integers(gshard, n))] if rng.random() < 0.6 else []
+    out.append((ctl, t, g))
+  return out
+
+
+@pytest.mark.parametrize('env', [{}, {'QH_WAVE_BITS': '2'}, {'QH_LANE_VALU': '2'}, {'QH_RELAYOUT': '0'}],
+                         ids=['default', 'WAVE_BITS=2', 'LANE_VALU=2', 'RELAYOUT=0'])
+def test_every_rank_plans_the_same_geometry(oracle, monkeypatch, env):
+  """The ranks of a sharded state exchange amplitudes block by block: they must agree on the sweeps, the tile
+  bits of each, the slabs and -- with relayout sweeps -- on where every index bit lives afterwards, although
+  each rank executes a different subset of the gates.  The planner keeps rank-dependent gates
+  as ghosts (planner.h GateRec::ghost); here: identical geometry on every shard, and the right amplitudes."""
+  for k, v in env.items():
+    monkeypatch.setenv(k, v)
+  rng = np.random.default_rng(zlib.crc32(repr(sorted(env.items())).encode()) + 7)
+  for case in range(10):
+    gshard = 1 + case % 3
+    n = int(rng.integers(11, 15)) + gshard
+    nloc = n - gshard
+    stream = _shard_variant_stream(rng, n, int(rng.integers(30, 200)), gshard)
+    psi = rng.standard_normal(1 << n) + 1j * rng.standard_normal(1 << n)
+    psi = (psi / np.linalg.norm(psi)).astype(np.complex128)
+    want = psi.copy()
+    _oracle_apply(oracle, want, n, stream)
+    got = np.empty_like(psi)
+    ref_geom = None
+    for shard in range(1 << gshard):
+      sweeps = _planned(n, nloc, shard, stream)
+      geom = [[(k, sp[k]) for k in GEOMETRY_KEYS] for sp in sweeps]
+      if ref_geom is None:
+        ref_geom = geom
+      assert geom == ref_geom, (env, case, shard, 'the ranks would disagree about an exchange')
+      part = psi[shard << nloc: (shard + 1) << nloc].copy()
+      plan_interp.run_plan(part, sweeps, nloc, shard)
+      got[shard << nloc: (shard + 1) << nloc] = part
+    err = float(np.max(np.abs(got - want)))
+    assert err < 1e-11, (env, case, n, gshard, err)
