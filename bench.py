@@ -8,7 +8,10 @@ gate submitted through the C-ABI (qh_apply1 / qh_applyc), state resident in HBM.
 
   python bench.py --gpus N --steps K --warmup W
   N = 1: BASELINE config 2, the 30-qubit QFT (the headline and the roofline kernel); the line also
-         carries `ladder_base` = the 33-qubit QFT on the same GPU, the N=1 point of config 5's ladder.
+         carries `ladder_base` = the 33-qubit QFT on the same GPU, the N=1 point of config 5's ladder,
+         `configs` = the other single-GPU BASELINE configurations timed the same way (config 3 supremacy-30,
+         config 4 Grover-34, and the QFT at the reference's default width complex64), each with its own
+         roofline, and `single_shot_ms` = ONE qft on a cold queue, planning included, followed by a read.
   N > 1: launched by torch.distributed.run, one rank per GPU; BASELINE config 5's ladder --
          34 / 35 / 36 qubits on 2 / 4 / 8 GPUs, the state sharded by its top log2(N) index bits,
          2^33 amplitudes = 128 GiB per GPU (weak scaling).  --qubits overrides.
@@ -48,6 +51,7 @@ def parse():
   ap.add_argument('--qubits', type=int, default=0,
                   help='default: 30 on one GPU (BASELINE config 2); 33 + log2(gpus) on several (config 5 ladder)')
   ap.add_argument('--no-ladder-base', action='store_true', help='N=1: skip the extra 33-qubit measurement')
+  ap.add_argument('--no-configs', action='store_true', help='N=1: skip configs 3, 4, complex64 and the single-shot timing')
   ap.add_argument('--fusion', type=int, default=-1, help='0 per-gate kernels, 1 fused sweeps (default)')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-cached-plan', action='store_true', help='skip the extra steps timed with the plan cache on')
@@ -179,9 +183,11 @@ def timed_steps(eng, ops, g8, steps, warmup, dist):
     dist.barrier()
   t0 = time.perf_counter()
   eng.timer_begin()
+  eng.timer_lap()
   for _ in range(steps):
     eng.run_stream(ops, g8)
     eng.flush()
+    eng.timer_lap()          # an event on the stream per step (no host wait): the per-step times behind `median`
   ev_ms = eng.timer_end()  # flushes + waits for the stream
   eng.sync()
   if dist is not None:
@@ -194,7 +200,9 @@ def timed_steps(eng, ops, g8, steps, warmup, dist):
     t = torch.tensor([wall], dtype=torch.float64, device=eng._red_device())
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall = float(t.item())
-  return wall, ev_ms, eng.stats()
+  st = eng.stats()
+  st['step_ms'] = eng.timer_laps()
+  return wall, ev_ms, st
 
 
 def ladder_base(device_index, fusion, steps=3):
@@ -213,9 +221,99 @@ def ladder_base(device_index, fusion, steps=3):
     norm2 = eng.norm2()
   units = 2 ** (n - 30)
   return {'qubits': n, 'gates_per_step': len(ops), 'steps': steps, 'ms_per_step': wall / steps * 1e3,
+          'median_ms_per_step': float(np.median(st['step_ms'])) if st['step_ms'] else None,
           'value': len(ops) * steps * units / wall, 'unit': 'gate-applies/s (2^30-amplitude units)',
           'kernels_per_step': st['kernels_launched'] / steps,
-          'hbm_GBps_swept': st['bytes_swept'] / (ev_ms * 1e-3) / 1e9, 'norm2': norm2}
+          'hbm_GBps_swept': st['bytes_swept'] / (ev_ms * 1e-3) / 1e9,
+          'roofline_frac': st['bytes_swept'] / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 'norm2': norm2}
+
+
+def config_line(name, n, bw, ops, g8, init, device_index, steps, warmup, note):
+  """One of the other single-GPU BASELINE configurations, timed like the headline: W warm-up steps, K timed steps
+  (wall clock between device syncs; HIP events per step), planned from scratch every step.  Its own roofline:
+  bytes per k_sweep launch from the plans (engine stats), average launch duration from the HIP events."""
+  from qcc_amd import device, native
+  try:
+    eng = device.DeviceState(n, bw, device=device_index, fusion=native.QH_FUSE_SWEEP)
+  except native.QhError as e:
+    return {'workload': name, 'qubits': n, 'skipped': str(e)}
+  with eng:
+    eng.init_basis(init)
+    wall, ev_ms, st = timed_steps(eng, ops, g8, steps, warmup, None)
+    norm2 = eng.norm2()
+  launches = max(1, st['kernels_launched'])
+  bytes_l = st['bytes_swept'] / launches
+  ms_l = ev_ms / launches
+  return {'workload': name, 'qubits': n, 'dtype': 'f64' if bw == 128 else 'f32', 'gates_per_step': len(ops), 'steps': steps,
+          'warmup': warmup, 'ms_per_step': wall / steps * 1e3,
+          'median_ms_per_step': float(np.median(st['step_ms'])) if st['step_ms'] else None,
+          'event_ms_per_step': ev_ms / steps, 'gate_applies_per_s': len(ops) * steps / wall,
+          'sweeps_per_step': st['sweeps'] / steps,
+          'effective_GBps_algorithmic': st['bytes_algorithmic'] / wall / 1e9,
+          'roofline': {'bound': 'hbm', 'kernel': 'k_sweep', 'achieved': bytes_l / (ms_l * 1e-3) / 1e9, 'peak': HBM_PEAK_GBPS,
+                       'unit': 'GB/s', 'frac': bytes_l / (ms_l * 1e-3) / 1e9 / HBM_PEAK_GBPS, 'avg_launch_ms': ms_l,
+                       'bytes_per_launch': bytes_l, 'traffic': None},
+          'norm2': norm2, 'note': note}
+
+
+def other_configs(device_index):
+  from qcc_amd import workloads
+  out = {}
+  ops, g8 = workloads.supremacy_stream(30, 20, seed=0).arrays()
+  out['config3_supremacy30_d20_seed0'] = config_line(
+      '30-qubit supremacy.py random circuit, depth 20, random.seed(0) [BASELINE config 3]', 30, 128, ops, g8, 0, device_index, 5, 2,
+      'op-heavy sweeps: bound by FP64 issue at the board power limit, not by HBM (DESIGN 4.3 / 7)')
+  ops, g8 = workloads.qft_stream(range(30)).arrays()
+  out['qft30_complex64'] = config_line(
+      '30-qubit QFT at the reference\'s default width complex64 (src/lib/tensor.py:28)', 30, 64, ops, g8,
+      0x12CB9A5E3 & ((1 << 30) - 1), device_index, 10, 3, 'state = 8 GiB; same gate stream as the headline')
+  nb = 17
+  ops, g8 = workloads.grover_stream(nb, [1, 0] * 8 + [1], iterations=1).arrays()
+  out['config4_grover34_one_iteration'] = config_line(
+      '34-qubit Grover (nbits 17), one iteration = oracle + diffusion, 256 GiB state [BASELINE config 4]', 2 * nb, 128, ops, g8,
+      workloads.grover_initial_index(nb), device_index, 2, 1, 'in place: no room for a second buffer beside 256 GiB')
+  return out
+
+
+def single_shot(device_index):
+  """ONE 30-qubit QFT on an idle engine followed by a read: nothing hides the planner here.  (a) through the API
+  mirror: circuit.qc().qft(reg) + maxprob(), Python gate construction included; (b) through the C-ABI: the gate
+  stream submitted with one qh_apply_stream call, then qh_sync."""
+  from qcc_amd import device, native, workloads
+  from qcc_amd.lib import circuit, tensor
+  out = {}
+  try:
+    n = 30
+    tensor.set_tensor_width(128)
+    os.environ['QH_PLAN_CACHE'] = '0'
+    times = []
+    for rep in range(3):
+      qc = circuit.qc('single-shot')
+      reg = qc.reg(n, 0x12CB9A5E3 & ((1 << n) - 1) if rep == 0 else rep)
+      qc.maxprob()                             # state built on the device, engine idle
+      t0 = time.perf_counter()
+      qc.qft(reg)
+      bits, p = qc.maxprob()
+      times.append((time.perf_counter() - t0) * 1e3)
+      del qc
+    out['qc_qft_then_maxprob_ms'] = {'runs': times, 'median': float(np.median(times))}
+    ops, g8 = workloads.qft_stream(range(n)).arrays()
+    times = []
+    with device.DeviceState(n, 128, device=device_index, fusion=native.QH_FUSE_SWEEP) as st:
+      for rep in range(4):
+        st.init_basis(5 + rep)
+        st.sync()
+        t0 = time.perf_counter()
+        st.run_stream(ops, g8)
+        st.sync()
+        times.append((time.perf_counter() - t0) * 1e3)
+    out['c_abi_stream_then_sync_ms'] = {'runs': times, 'median': float(np.median(times[1:])),
+                                        'note': 'first run allocates the second buffer and the op buffers'}
+  except Exception as e:  # pylint: disable=broad-except
+    out['error'] = repr(e)
+  finally:
+    tensor.set_tensor_width(None)
+  return out
 
 
 def main():
@@ -317,6 +415,8 @@ def main():
         'hbm_GBps_swept': stats['bytes_swept'] / wall / 1e9,
         'kernels_per_step': stats['kernels_launched'] / steps,
         'event_ms_per_step': ev_ms / steps, 'norm2': norm2,
+        'median_ms_per_step': float(np.median(stats['step_ms'])) if stats.get('step_ms') else None,
+        'step_ms_min_max': [float(min(stats['step_ms'])), float(max(stats['step_ms']))] if stats.get('step_ms') else None,
         'roofline': roofline,
     }
     if cached:
@@ -336,6 +436,9 @@ def main():
   if rank == 0:
     if world == 1 and dist is None and n == 30 and not args.no_ladder_base and fusion != native.QH_FUSE_OFF:
       out['ladder_base'] = ladder_base(local_rank, fusion)
+    if world == 1 and dist is None and n == 30 and not args.no_configs and fusion != native.QH_FUSE_OFF:
+      out['configs'] = other_configs(local_rank)
+      out['single_shot_ms'] = single_shot(local_rank)
     if not args.no_cpu_baseline and world == 1:
       out['cpu_baseline'] = cpu_baseline(args, ops, g8)
       out['gpu_over_cpu'] = out['whole_state_gate_applies_per_s'] / out['cpu_baseline']['value']

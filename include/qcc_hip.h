@@ -232,6 +232,11 @@ int qh_reset_stats(qh_handle h);
 /* hipEvent pair on the handle's stream.                                      */
 int qh_timer_begin(qh_handle h);
 int qh_timer_end(qh_handle h, float *milliseconds);
+/* Lap marks: qh_timer_lap flushes what is queued and records an event on the stream (no host wait);
+ * qh_timer_laps waits for the last mark, writes the milliseconds between consecutive marks (at most cap),
+ * sets *count to the number of intervals and forgets the marks.  Per-step times of a loop without stalling it. */
+int qh_timer_lap(qh_handle h);
+int qh_timer_laps(qh_handle h, float *milliseconds, int cap, int *count);
 /* JSON text of the sweeps the planner would launch for the current queue
  * (does not launch or clear).  Returns bytes needed; writes at most cap.     */
 int qh_plan_json(qh_handle h, char *buf, uint64_t cap, uint64_t *needed);

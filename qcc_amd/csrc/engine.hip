@@ -64,6 +64,8 @@ struct qh_state_s {
   std::vector<qh::GateRec> queue;
   qh_stats stats{};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::vector<hipEvent_t> laps;   // qh_timer_lap: events on the stream, read back by qh_timer_laps
+  size_t laps_used = 0;
   double *d_red = nullptr;     // kRedBlocks doubles
   uint64_t *d_redi = nullptr;  // kRedBlocks u64
   qh::SweepBuffers sweep;      // device/pinned op buffers for fused sweeps
@@ -639,6 +641,7 @@ int qh_destroy(qh_handle h) {
     if (h->d_redi) (void)hipFree(h->d_redi);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    for (hipEvent_t e : h->laps) (void)hipEventDestroy(e);
     if (h->owns_mem && h->d_psi) (void)hipFree(h->d_psi);
     if (h->d_alt) (void)hipFree(h->d_alt);
     if (h->host_psi) (void)hipHostFree(h->host_psi);
@@ -1089,6 +1092,30 @@ int qh_timer_end(qh_handle h, float *ms) {
   HIP_TRY(hipEventRecord(h->ev1, h->stream));
   HIP_TRY(hipEventSynchronize(h->ev1));
   HIP_TRY(hipEventElapsedTime(ms, h->ev0, h->ev1));
+  return QH_OK;
+}
+
+int qh_timer_lap(qh_handle h) {
+  if (!h || h->dry) return fail(QH_ERR_ARG, "null/dry");
+  HIP_TRY(hipSetDevice(h->device));
+  int rc = flush_impl(h);
+  if (rc) return rc;
+  if (h->laps_used == h->laps.size()) {
+    hipEvent_t e = nullptr;
+    HIP_TRY(hipEventCreate(&e));
+    h->laps.push_back(e);
+  }
+  HIP_TRY(hipEventRecord(h->laps[h->laps_used++], h->stream));
+  return QH_OK;
+}
+int qh_timer_laps(qh_handle h, float *ms, int cap, int *count) {
+  if (!h || !count || h->dry) return fail(QH_ERR_ARG, "null/dry");
+  HIP_TRY(hipSetDevice(h->device));
+  const int n = h->laps_used > 0 ? (int)h->laps_used - 1 : 0;
+  if (h->laps_used) HIP_TRY(hipEventSynchronize(h->laps[h->laps_used - 1]));
+  for (int k = 0; k < n && ms && k < cap; ++k) HIP_TRY(hipEventElapsedTime(&ms[k], h->laps[k], h->laps[k + 1]));
+  *count = n;
+  h->laps_used = 0;
   return QH_OK;
 }
 

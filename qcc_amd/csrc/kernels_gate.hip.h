@@ -28,7 +28,7 @@
 
 namespace qh {
 
-constexpr int kMaxIns = 12;
+constexpr int kMaxIns = 14;   // (the planner folds at most 12 into a plan: two are left for the slab bits of a launch around an exchange)
 
 // Sorted (ascending) list of bit positions at which a bit is inserted into a
 // dense work-item counter to form an amplitude index; `ones` has the inserted

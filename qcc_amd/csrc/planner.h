@@ -60,7 +60,7 @@ constexpr int kMaxRegBits = 6; // complex128: 5 (32 amplitudes = 128 VGPRs of da
 inline int max_reg_bits(int bw) { return bw == 128 ? 5 : 6; }
 constexpr int kMaxWaveBits = 2; // index bits selected by the wave id inside a workgroup ("super-tile", see OP_WSWAP)
 constexpr int kMaxSweepOps = 1024;
-constexpr int kMaxInsertBits = 12;  // == kMaxIns of kernels_gate.hip.h (tile enumeration)
+constexpr int kMaxInsertBits = 12;  // <= kMaxIns of kernels_gate.hip.h (tile enumeration; slab launches add up to 3 more)
 
 enum : uint32_t { OP_DENSE_REG = 0, OP_DENSE_LANE = 1, OP_DIAG = 2,
                   OP_LSWAP = 3,    // lane bit tb (4|5) <-> register bit cm_reg (v_permlane swaps)
@@ -240,10 +240,13 @@ class Planner {
     if (wave_bits >= 0) max_wave_ = std::min(wave_bits, kMaxWaveBits);
   }
 
-  PlanResult plan(const std::vector<GateRec> &queue) {
-    PlanResult out;
+  // The gates of the queue as the sweeps will see them: shard bits resolved, the reference's 5-gate Toffolis
+  // fused, X gates turned into pending flips (fills weight_; *noops counts the gates that vanished).
+  void prepare(const std::vector<GateRec> &queue, std::vector<GateRec> *pending_out, std::vector<uint64_t> *alg_out, uint64_t *noops) {
+    struct { uint64_t noop_gates = 0; } out;
     std::vector<GateRec> pending;
     pending.reserve(queue.size());
+    alg_override_.clear();
     const uint64_t lm = (1ull << nloc_) - 1;
     for (const auto &q : queue) {
       // resolve shard-index bits now: they are constants on this rank.  A gate that does nothing HERE (its
@@ -288,10 +291,53 @@ class Planner {
     std::vector<uint64_t> alg = alg_override_;
     std::vector<uint32_t> weight(pending.size(), 1);
     for (size_t i = 0; i < pending.size(); ++i) if (pending[i].ghost) weight[i] = 0;
-    std::vector<int> first_tile;
     fuse_sleator_weinfurter(&pending, &alg, &weight);
     if (propagate_x_) propagate_x(&pending, &alg, &weight, &out.noop_gates);
     weight_.swap(weight);
+    pending_out->swap(pending);
+    alg_out->swap(alg);
+    *noops = out.noop_gates;
+  }
+
+  // How many sweeps plan() would launch, and whether one of them has a far tile (plan_has_far_tile), from the
+  // tile selection alone -- no ops are emitted, no index bit is relabelled (with relayout only the first sweep
+  // can then have a far tile: later ones gather from wherever and the check is skipped for them).  A tenth of a
+  // full plan: what plan_best needs to pick the number of wave bits.
+  void skeleton(const std::vector<GateRec> &queue, size_t *nsweeps, bool *far_tile) {
+    std::vector<GateRec> pending;
+    std::vector<uint64_t> alg;
+    uint64_t noops = 0;
+    prepare(queue, &pending, &alg, &noops);
+    *nsweeps = 0;
+    *far_tile = false;
+    const uint64_t always = (1ull << lane_low_) - 1;
+    while (!pending.empty()) {
+      std::vector<int> sel, lanehi, regs, waves;
+      select_tile_bits(pending, &sel);
+      assign_bits(sel, &lanehi, &regs, &waves);
+      if (!relayout_ || *nsweeps == 0) {
+        int far = 0;
+        for (int b : lanehi) far += b >= 25;
+        for (int b : regs) far += b >= 25;
+        if (far >= 8) *far_tile = true;
+      }
+      std::vector<uint8_t> flags(pending.size(), 0);
+      pass(pending, always | mask_of(lanehi) | mask_of(regs) | mask_of(waves), pending.size(), &flags);
+      std::vector<GateRec> rest;
+      for (size_t i = 0; i < pending.size(); ++i) if (!flags[i]) rest.push_back(pending[i]);
+      if (rest.size() == pending.size()) rest.erase(rest.begin());     // (as build_sweep: never loop forever)
+      pending.swap(rest);
+      ++*nsweeps;
+    }
+  }
+
+  PlanResult plan(const std::vector<GateRec> &queue) {
+    PlanResult out;
+    std::vector<GateRec> pending;
+    std::vector<uint64_t> alg;
+    prepare(queue, &pending, &alg, &out.noop_gates);
+    const uint64_t lm = (1ull << nloc_) - 1;
+    std::vector<int> first_tile;
     while (!pending.empty()) {
       std::vector<GateRec> rest;
       std::vector<uint64_t> rest_alg;
@@ -618,32 +664,91 @@ class Planner {
     return m;
   }
 
+  // assign_bits() as a predicate on a bit mask (no vectors: called for every candidate of every round)
+  bool tile_fits(uint64_t selmask) const {
+    const uint64_t lowmask = ((1ull << kLaneBits) - 1) & ~((1ull << lane_low_) - 1);
+    const int nlow = popc(selmask & lowmask);
+    uint64_t other = selmask & ~lowmask;
+    const int nother = popc(other);
+    const int extra = std::max(0, nother - rb_cap_);
+    const int nw = std::min(extra, max_wave_);
+    const int need_move = extra - nw;
+    if (need_move == 0) return nlow <= lane_hi_;
+    if (!split_lanes_ || nlow + need_move > lane_hi_) return false;
+    for (int k = 0; k < nw; ++k) other &= other - 1;          // split-lane tile: the lowest bits go to the wave id
+    const uint64_t reach = (kMaxLaneHiBit >= 63) ? ~0ull : ((2ull << kMaxLaneHiBit) - 1);
+    if (__builtin_ctzll(other) >= 17 && lanes_high_) return popc(other & reach) >= need_move;
+    uint64_t t = other;
+    for (int k = 0; k < need_move; ++k) {
+      if (__builtin_ctzll(t) > kMaxLaneHiBit) return false;
+      t &= t - 1;
+    }
+    return true;
+  }
+
+  // pass() on precomputed per-gate masks (the inner loop of the tile-bit selection).  A candidate bit c can only
+  // change the outcome from the first dense gate on c that the current tile skips although nothing blocks it:
+  // the baseline pass records the state in front of that gate per bit, and a candidate's pass resumes there.
+  struct PassRec { uint64_t dense_bits, diag_bits; uint32_t score; int tgt; };
+  struct PassState { size_t idx = 0; uint64_t blocked_all = 0, blocked_diag = 0; size_t count = 0, score = 0; bool valid = false; };
+  size_t pass_fast(const std::vector<PassRec> &rec, uint64_t tilemask, const PassState &st, PassState *snaps = nullptr) const {
+    uint64_t blocked_all = st.blocked_all, blocked_diag = st.blocked_diag;
+    size_t count = st.count, score = st.score;
+    const size_t n = rec.size();
+    for (size_t i = st.idx; i < n; ++i) {
+      const PassRec &r = rec[i];
+      const bool can_pass = !(r.dense_bits & (blocked_all | blocked_diag)) && !(r.diag_bits & blocked_all);
+      const bool fits = count < (size_t)kMaxSweepOps && (!r.dense_bits || (tilemask & r.dense_bits));
+      if (can_pass && fits) {
+        ++count;
+        score += r.score;
+      } else {
+        if (snaps && can_pass && r.dense_bits && !snaps[r.tgt].valid) {
+          PassState &p = snaps[r.tgt];
+          p.idx = i; p.blocked_all = blocked_all; p.blocked_diag = blocked_diag; p.count = count; p.score = score; p.valid = true;
+        }
+        blocked_all |= r.dense_bits;
+        blocked_diag |= r.diag_bits;
+      }
+    }
+    return score;
+  }
+
   void select_tile_bits(const std::vector<GateRec> &pending, std::vector<int> *sel_out) const {
     const size_t window = std::min<size_t>(pending.size(), 4096);
     const uint64_t always = (1ull << lane_low_) - 1;
     std::vector<int> cand;       // dense target bits above bit 2, in order of first use
+    std::vector<PassRec> rec(window);
+    uint64_t seen = 0;
     for (size_t i = 0; i < window; ++i) {
       const GateRec &r = pending[i];
-      if (!plan_diag(r.g, r.tgt) && r.tgt >= lane_low_ &&
-          std::find(cand.begin(), cand.end(), r.tgt) == cand.end())
+      const bool diag = plan_diag(r.g, r.tgt);
+      const uint64_t tb = (r.tgt >= 0) ? (1ull << r.tgt) : 0;
+      rec[i] = PassRec{diag ? 0 : tb, r.ctl_mask | r.neg_mask | (diag ? tb : 0), (uint32_t)(diag ? 1 : dense_weight_), r.tgt};
+      if (!diag && r.tgt >= lane_low_ && !((seen >> r.tgt) & 1ull)) {
         cand.push_back(r.tgt);
+        seen |= 1ull << r.tgt;
+      }
     }
     std::vector<int> sel;
-    size_t best_total = pass(pending, always, window, nullptr);
+    uint64_t selmask = 0;
+    PassState snaps[64];
+    size_t best_total = pass_fast(rec, always, PassState(), snaps);
     while ((int)sel.size() < lane_hi_ + rb_cap_ + max_wave_) {
       int best_bit = -1;
       size_t best = best_total;
       for (int c : cand) {
-        if (std::find(sel.begin(), sel.end(), c) != sel.end()) continue;
-        std::vector<int> trial = sel, l, r, wv;
-        trial.push_back(c);
-        if (!assign_bits(trial, &l, &r, &wv)) continue;
-        const size_t sc = pass(pending, always | mask_of(trial), window, nullptr);
+        if ((selmask >> c) & 1ull) continue;
+        if (!snaps[c].valid) continue;                       // no gate on c waits for the tile: the score cannot change
+        if (!tile_fits(selmask | (1ull << c))) continue;
+        const size_t sc = pass_fast(rec, always | selmask | (1ull << c), snaps[c]);
         if (sc > best) { best = sc; best_bit = c; }
       }
       if (best_bit < 0) break;
       sel.push_back(best_bit);
-      best_total = best;
+      selmask |= 1ull << best_bit;
+      for (PassState &p : snaps) p.valid = false;
+      best_total = pass_fast(rec, always | selmask, PassState(), snaps);
     }
     sel_out->swap(sel);
   }
@@ -1266,12 +1371,24 @@ class Planner {
         g.tab_shift |= (uint32_t)shift << (8 * g.ntab);
         g.tab_off[g.ntab] = (uint32_t)(sp->tables.size() / 2);
         g.ntab++;
-        for (uint32_t v = 0; v < 256; ++v) {
-          double fr = 1, fi = 0;
-          for (auto &o : in)
-            if (((uint64_t)v << shift) & o.mask) cmul_acc(&fr, &fi, o.re, o.im);
-          sp->tables.push_back(fr);
-          sp->tables.push_back(fi);
+        // entry v = product of the factors of v's set bits, built by doubling: entry(v) = entry(v without its
+        // lowest set bit) x factor(that bit) -- the same products in the same order as a loop over the terms
+        // (terms of one bit were merged when they were collected)
+        double bf[8][2];
+        for (int b = 0; b < 8; ++b) { bf[b][0] = 1; bf[b][1] = 0; }
+        for (auto &o : in) {
+          const int b = __builtin_ctzll(o.mask) - shift;
+          cmul_acc(&bf[b][0], &bf[b][1], o.re, o.im);
+        }
+        const size_t t0 = sp->tables.size();
+        sp->tables.resize(t0 + 512);
+        double *tb = &sp->tables[t0];
+        tb[0] = 1; tb[1] = 0;
+        for (uint32_t v = 1; v < 256; ++v) {
+          const int hb = 31 - __builtin_clz(v);            // highest set bit: entry(v) = entry(v - 2^hb) x factor(hb)
+          double fr = tb[2 * (v ^ (1u << hb))], fi = tb[2 * (v ^ (1u << hb)) + 1];
+          cmul_acc(&fr, &fi, bf[hb][0], bf[hb][1]);
+          tb[2 * v] = fr; tb[2 * v + 1] = fi;
         }
       }
       g.oterm_off = (uint32_t)sp->oterms.size();
@@ -1425,6 +1542,26 @@ inline bool plan_has_far_tile(const PlanResult &pr) {
 inline PlanResult plan_best(const std::vector<GateRec> &queue, int nloc, uint64_t shard, int bw, int max_rb,
                             bool split_lanes, bool allow_relayout = false, bool keep_ghosts = false) {
   if (getenv("QH_WAVE_BITS")) return Planner(nloc, shard, bw, max_rb, split_lanes, -1, allow_relayout, keep_ghosts).plan(queue);
+  if (!env_flag("QH_PLAN_EXHAUSTIVE", false)) {
+    // the same choice from the tile selections alone (Planner::skeleton), then ONE full plan: a third of the
+    // planning time of three full plans (30-qubit QFT: 1.9 -> 0.9 ms)
+    int best_wb = 1;
+    size_t best_n = 0;
+    bool have = false, best_far = false;
+    for (int wb : {1, 2, 0}) {
+      size_t n = 0;
+      bool far = false;
+      Planner(nloc, shard, bw, max_rb, split_lanes, wb, allow_relayout, keep_ghosts).skeleton(queue, &n, &far);
+      if (!have || (best_far && !far) || (best_far == far && n < best_n)) {
+        best_wb = wb;
+        best_n = n;
+        best_far = far;
+        have = true;
+      }
+      if (best_n <= 1 && !best_far) break;
+    }
+    return Planner(nloc, shard, bw, max_rb, split_lanes, best_wb, allow_relayout, keep_ghosts).plan(queue);
+  }
   PlanResult best;
   bool have = false, best_far = false;
   for (int wb : {1, 2, 0}) {

@@ -315,6 +315,16 @@ class DeviceState:
     native.check(self.lib.qh_timer_end(self.h, ctypes.byref(ms)))
     return ms.value
 
+  def timer_lap(self):
+    native.check(self.lib.qh_timer_lap(self.h))
+
+  def timer_laps(self, cap=4096):
+    """Milliseconds between consecutive timer_lap() marks (waits for the last one)."""
+    buf = (ctypes.c_float * cap)()
+    n = ctypes.c_int(0)
+    native.check(self.lib.qh_timer_laps(self.h, buf, cap, ctypes.byref(n)))
+    return [float(buf[k]) for k in range(min(n.value, cap))]
+
   def plan_json(self):
     need = ctypes.c_uint64()
     native.check(self.lib.qh_plan_json(self.h, None, 0, ctypes.byref(need)))

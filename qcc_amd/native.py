@@ -80,6 +80,8 @@ SIGNATURES = {
     'qh_reset_stats': (_i32, [_vp]),
     'qh_timer_begin': (_i32, [_vp]),
     'qh_timer_end': (_i32, [_vp, ctypes.POINTER(ctypes.c_float)]),
+    'qh_timer_lap': (_i32, [_vp]),
+    'qh_timer_laps': (_i32, [_vp, ctypes.POINTER(ctypes.c_float), _i32, ctypes.POINTER(_i32)]),
     'qh_plan_json': (_i32, [_vp, ctypes.c_char_p, _u64, ctypes.POINTER(_u64)]),
     'qh_plan_export': (_i32, [_vp, _vp, _u64, ctypes.POINTER(_u64)]),
     'qh_host_apply1': (_i32, [_vp, _dp, _i32, _i32, _i32]),

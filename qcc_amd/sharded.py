@@ -584,6 +584,13 @@ class ShardedState:
   def timer_end(self):
     return self.eng.timer_end()
 
+  def timer_lap(self):
+    if hasattr(self.eng, 'timer_lap'):
+      self.eng.timer_lap()
+
+  def timer_laps(self):
+    return self.eng.timer_laps() if hasattr(self.eng, 'timer_laps') else []
+
   def stats(self):
     s = self.eng.stats()
     s['exchanges'] = self.exchanges

@@ -89,8 +89,8 @@ def test_loopback_exchange_equals_x_gate(oracle, monkeypatch, transport, pack, n
     assert xs['sweeps_overlapped'] >= 1   # at least one neighbouring sweep was cut into slabs
 
 
-@pytest.mark.parametrize('relayout', ['1', '0'])
-def test_loopback_exchange_at_shard_size(monkeypatch, relayout, capsys):
+@pytest.mark.parametrize('relayout,pack', [('1', 'auto'), ('1', 'packed'), ('0', 'auto')])
+def test_loopback_exchange_at_shard_size(monkeypatch, relayout, pack, capsys):
   """Config 5's exchange leg at FULL shard size on one GPU (VERDICT r2, next #1a): a 2^33-amplitude handle with a
   1-rank RCCL communicator sends the two 64-GiB halves selected by its top logical bit to itself -- default
   chunk, 8 slabs, 2 x 256 rounds of grouped ncclSend/ncclRecv, the staging halves, the landing copies (or, with
@@ -99,6 +99,8 @@ def test_loopback_exchange_at_shard_size(monkeypatch, relayout, capsys):
   an X gate on that bit; the circuit around it is a QFT, so the exact product-state oracle checks the result."""
   from tests.product_oracle import ProductState
   monkeypatch.setenv('QH_RELAYOUT', relayout)
+  if pack == 'packed':
+    monkeypatch.setenv('QH_EXCHANGE_PACK', '1')
   n, bit = 33, 32
   try:
     st = device.DeviceState(n, 128, fusion=native.QH_FUSE_SWEEP)
@@ -130,7 +132,7 @@ def test_loopback_exchange_at_shard_size(monkeypatch, relayout, capsys):
                           [0, (1 << n) - 512] + [int(v) for v in rng.integers(0, (1 << n) - 512, size=24)]])
     amp = np.array([st.amplitude(int(i)) for i in idx[::16]])      # by logical index: no re-layout pass
     with capsys.disabled():
-      print(f'\n[exchange @2^33, QH_RELAYOUT={relayout}] span_ms={xs["span_ms"]:.1f} rounds={xs["rounds"]} packed={xs["rounds_packed"]} '
+      print(f'\n[exchange @2^33, QH_RELAYOUT={relayout} pack={pack}] span_ms={xs["span_ms"]:.1f} rounds={xs["rounds"]} packed={xs["rounds_packed"]} '
             f'slabs={xs["slabs"]} sweeps_overlapped={xs["sweeps_overlapped"]} sweeps={s["sweeps"]} '
             f'GB/s(one way)={xs["bytes_sent"] / max(xs["span_ms"], 1e-9) / 1e6:.0f}')
   want = ps.amplitudes(idx[::16])
@@ -140,7 +142,8 @@ def test_loopback_exchange_at_shard_size(monkeypatch, relayout, capsys):
   assert xs['exchanges'] == 1 and xs['bytes_sent'] == (1 << n) * 16 and xs['slabs'] == 8
   assert xs['rounds'] == (1 << (n - 1)) >> 22            # half the shard per move, 2^22 amplitudes per round
   assert xs['sweeps_overlapped'] == 2                    # the sweep before and the sweep after ran slab by slab
-  assert (xs['rounds_packed'] > 0) == (relayout == '1')
+  if pack == 'packed':
+    assert xs['rounds_packed'] == xs['rounds']
 
 
 def test_exchange_needs_a_communicator():
