@@ -230,6 +230,9 @@ inline int unit_segments(const SweepPlan &sp, int nloc, uint64_t *masks, int *sh
 
 class Planner {
  public:
+  // one gate as the tile selection sees it (pass_fast / search_run), and the state of a pass in front of a gate
+  struct PassRec { uint64_t dense_bits, diag_bits; uint32_t score; int tgt; };
+  struct PassState { size_t idx = 0; uint64_t blocked_all = 0, blocked_diag = 0; size_t count = 0, score = 0; bool valid = false; };
   Planner(int nloc, uint64_t shard, int bw, int max_rb, bool split_lanes = true, int wave_bits = -1,
           bool allow_relayout = false, bool keep_ghosts = false)
       : nloc_(nloc), shard_(shard), amp_bytes_(bw == 128 ? 16 : 8), split_lanes_(split_lanes),
@@ -303,7 +306,7 @@ class Planner {
   // tile selection alone -- no ops are emitted, no index bit is relabelled (with relayout only the first sweep
   // can then have a far tile: later ones gather from wherever and the check is skipped for them).  A tenth of a
   // full plan: what plan_best needs to pick the number of wave bits.
-  void skeleton(const std::vector<GateRec> &queue, size_t *nsweeps, bool *far_tile) {
+  void skeleton(const std::vector<GateRec> &queue, size_t *nsweeps, bool *far_tile, std::vector<uint64_t> *tiles_out = nullptr) {
     std::vector<GateRec> pending;
     std::vector<uint64_t> alg;
     uint64_t noops = 0;
@@ -323,6 +326,7 @@ class Planner {
       }
       std::vector<uint8_t> flags(pending.size(), 0);
       pass(pending, always | mask_of(lanehi) | mask_of(regs) | mask_of(waves), pending.size(), &flags);
+      if (tiles_out) tiles_out->push_back(mask_of(sel));
       std::vector<GateRec> rest;
       for (size_t i = 0; i < pending.size(); ++i) if (!flags[i]) rest.push_back(pending[i]);
       if (rest.size() == pending.size()) rest.erase(rest.begin());     // (as build_sweep: never loop forever)
@@ -330,6 +334,122 @@ class Planner {
       ++*nsweeps;
     }
   }
+
+  // ---- tile search ---------------------------------------------------------------------------------------
+  // The greedy selection maximises the gates of ONE sweep; layered circuits (supremacy: every qubit couples to
+  // its grid neighbours every few layers) can need a sweep less when an early sweep takes FEWER gates but leaves
+  // the frontier where the next one runs long (BASELINE config 3, seed 0: greedy 85+88+79+84+6 gates in 5 sweeps;
+  // 66+128+80+68 in 4 exists).  search_tiles() looks for K = greedy - 1 tiles that empty the queue: local search
+  // from the greedy tiles on the planner's own pass model -- replace a tile bit that ran few dense gates in its
+  // sweep by a bit whose gates were ready but not in the tile, accept if no more gates are left over than before,
+  // restart from the best tiles when stuck.  Deterministic (fixed seed, budget counted in gate visits, not in
+  // time: the ranks of a sharded state must find the same tiles).  Returns true and the tiles (bit numbering of
+  // the start of the flush) on success.
+  struct SearchSweep { std::vector<PassRec> rest; uint32_t cnt[64]; uint64_t want; };
+  void search_run(const std::vector<PassRec> &rec, uint64_t tilemask, SearchSweep *out, uint64_t *steps) const {
+    uint64_t blocked_all = 0, blocked_diag = 0;
+    out->rest.clear();
+    memset(out->cnt, 0, sizeof out->cnt);
+    out->want = 0;
+    *steps += rec.size();
+    for (const PassRec &r : rec) {
+      const bool can_pass = !(r.dense_bits & (blocked_all | blocked_diag)) && !(r.diag_bits & blocked_all);
+      if (can_pass && (!r.dense_bits || (tilemask & r.dense_bits))) {
+        if (r.dense_bits) out->cnt[r.tgt]++;
+      } else {
+        if (can_pass && r.dense_bits) out->want |= r.dense_bits;
+        blocked_all |= r.dense_bits;
+        blocked_diag |= r.diag_bits;
+        out->rest.push_back(r);
+      }
+    }
+  }
+  bool search_tiles(const std::vector<GateRec> &queue, const std::vector<uint64_t> &greedy_tiles, uint64_t step_budget,
+                    std::vector<std::vector<int>> *tiles_out) {
+    const size_t K = greedy_tiles.size() - 1;
+    if (K < 2) return false;
+    std::vector<GateRec> pending;
+    std::vector<uint64_t> alg;
+    uint64_t noops = 0;
+    prepare(queue, &pending, &alg, &noops);
+    std::vector<PassRec> rec0(pending.size());
+    uint64_t dense_used = 0;
+    for (size_t i = 0; i < pending.size(); ++i) {
+      const GateRec &r = pending[i];
+      const bool diag = plan_diag(r.g, r.tgt);
+      const uint64_t tb = (r.tgt >= 0) ? (1ull << r.tgt) : 0;
+      rec0[i] = PassRec{diag ? 0 : tb, r.ctl_mask | r.neg_mask | (diag ? tb : 0), 1, r.tgt};
+      if (!diag) dense_used |= tb;
+    }
+    const uint64_t always = (1ull << lane_low_) - 1;
+    const uint64_t movable = dense_used & ~always;
+    const int cap = lane_hi_ + rb_cap_ + max_wave_;
+    if ((size_t)popc(movable) > K * (size_t)cap) return false;       // not even room to visit every qubit once
+    uint64_t rng = 0x9e3779b97f4a7c15ull;
+    auto rnd = [&](uint32_t n) { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return (uint32_t)((rng >> 11) % n); };
+    auto pick_bit = [&](uint64_t m) { int k = (int)rnd((uint32_t)popc(m)); while (k--) m &= m - 1; return __builtin_ctzll(m); };
+    std::vector<uint64_t> cur(greedy_tiles.begin(), greedy_tiles.begin() + (long)K), best_tiles;
+    for (uint64_t &t : cur) t &= ~always;
+    std::vector<SearchSweep> st(K), trial(K);
+    uint64_t steps = 0;
+    auto eval_from = [&](const std::vector<uint64_t> &tiles, size_t from, std::vector<SearchSweep> *out) {
+      for (size_t i = from; i < K; ++i) search_run(i ? (*out)[i - 1].rest : rec0, always | tiles[i], &(*out)[i], &steps);
+      return (*out)[K - 1].rest.size();
+    };
+    size_t cv = eval_from(cur, 0, &st), best = cv;
+    best_tiles = cur;
+    size_t since_improved = 0, walks_without_gain = 0;
+    while (best > 0 && steps < step_budget && walks_without_gain < 4) {
+      const size_t i = rnd((uint32_t)K);
+      const uint64_t s = cur[i];
+      uint64_t wantb = st[i].want & ~s & movable;
+      if (!wantb || rnd(100) < 15) wantb = movable & ~s;
+      if (!wantb) continue;
+      uint64_t ns = s | (1ull << pick_bit(wantb));
+      if (popc(s) >= cap || rnd(100) >= 70) {
+        if (!s) continue;
+        uint32_t m = ~0u;
+        for (uint64_t t = s; t; t &= t - 1) m = std::min(m, st[i].cnt[__builtin_ctzll(t)]);
+        const uint32_t slack = rnd(100) < 30 ? 1 : 0;
+        uint64_t pool = 0;
+        for (uint64_t t = s; t; t &= t - 1) if (st[i].cnt[__builtin_ctzll(t)] <= m + slack) pool |= t & -t;
+        ns &= ~(1ull << pick_bit(pool));
+      }
+      if (ns == s || popc(ns) > cap || !tile_fits(ns)) continue;
+      for (size_t k = 0; k < i; ++k) trial[k].rest.clear();          // (prefix unchanged: evaluated from sweep i on)
+      std::vector<uint64_t> cand = cur;
+      cand[i] = ns;
+      // sweeps before i are those of `st`: run i.. on top of st[i-1]
+      {
+        const std::vector<PassRec> *src = i ? &st[i - 1].rest : &rec0;
+        search_run(*src, always | cand[i], &trial[i], &steps);
+        for (size_t k = i + 1; k < K; ++k) search_run(trial[k - 1].rest, always | cand[k], &trial[k], &steps);
+      }
+      const size_t v = trial[K - 1].rest.size();
+      if (v <= cv) {
+        for (size_t k = i; k < K; ++k) std::swap(st[k], trial[k]);
+        cur.swap(cand);
+        if (v < cv) since_improved = 0;
+        cv = v;
+        if (v < best) { best = v; best_tiles = cur; walks_without_gain = 0; }
+      }
+      if (++since_improved > 1500) {        // stuck on a plateau: back to the best tiles, another walk
+        cur = best_tiles;
+        cv = eval_from(cur, 0, &st);
+        since_improved = 0;
+        ++walks_without_gain;               // (four walks from the best tiles without a better one: give up)
+      }
+    }
+    if (best > 0) return false;
+    tiles_out->clear();
+    for (uint64_t t : best_tiles) {
+      std::vector<int> b;
+      for (; t; t &= t - 1) b.push_back(__builtin_ctzll(t));
+      tiles_out->push_back(b);
+    }
+    return true;
+  }
+  void set_tiles(const std::vector<std::vector<int>> &t) { tiles_ = t; }
 
   PlanResult plan(const std::vector<GateRec> &queue) {
     PlanResult out;
@@ -342,7 +462,14 @@ class Planner {
       std::vector<GateRec> rest;
       std::vector<uint64_t> rest_alg;
       std::vector<uint32_t> rest_w;
-      out.sweeps.push_back(build_sweep(pending, alg, &rest, &rest_alg, &rest_w));
+      std::vector<int> forced;
+      const std::vector<int> *fs = nullptr;
+      if (out.sweeps.size() < tiles_.size()) {          // tiles chosen for the whole flush (QH_FORCE_TILES / the tile search),
+        for (int b : tiles_[out.sweeps.size()])         // in the bit numbering the flush started with
+          if (b >= lane_low_ && b < nloc_) forced.push_back(out.final_pos[b]);
+        fs = &forced;
+      }
+      out.sweeps.push_back(build_sweep(pending, alg, &rest, &rest_alg, &rest_w, fs));
       if (out.sweeps.size() == 1) {     // where this flush began: see the last sweep below
         const SweepPlan &f = out.sweeps[0];
         for (int k = 0; k < f.nlanehi(); ++k) first_tile.push_back(f.lanehi[k]);
@@ -412,6 +539,18 @@ class Planner {
   bool lookahead_ = env_flag("QH_RELAYOUT_AHEAD", true); // see finish_relayout
   std::vector<uint64_t> alg_override_;
   std::vector<uint32_t> weight_;  // reference gate applications each pending record stands for
+  std::vector<std::vector<int>> tiles_ = parse_tiles(getenv("QH_FORCE_TILES"));   // "3,6,7;12,13" = tile bits of sweep 0; sweep 1 (experiments)
+  static std::vector<std::vector<int>> parse_tiles(const char *s) {
+    std::vector<std::vector<int>> out;
+    if (!s || !*s) return out;
+    out.emplace_back();
+    for (const char *p = s; *p;) {
+      if (*p == ';') { out.emplace_back(); ++p; }
+      else if (*p == ',' || *p == ' ') ++p;
+      else { char *e; out.back().push_back((int)strtol(p, &e, 10)); if (e == p) break; p = e; }
+    }
+    return out;
+  }
 
   static bool near(double a, double b) { return std::fabs(a - b) <= 4e-15; }
   static bool same_gate(const double a[8], const double b[8]) {
@@ -689,8 +828,6 @@ class Planner {
   // pass() on precomputed per-gate masks (the inner loop of the tile-bit selection).  A candidate bit c can only
   // change the outcome from the first dense gate on c that the current tile skips although nothing blocks it:
   // the baseline pass records the state in front of that gate per bit, and a candidate's pass resumes there.
-  struct PassRec { uint64_t dense_bits, diag_bits; uint32_t score; int tgt; };
-  struct PassState { size_t idx = 0; uint64_t blocked_all = 0, blocked_diag = 0; size_t count = 0, score = 0; bool valid = false; };
   size_t pass_fast(const std::vector<PassRec> &rec, uint64_t tilemask, const PassState &st, PassState *snaps = nullptr) const {
     uint64_t blocked_all = st.blocked_all, blocked_diag = st.blocked_diag;
     size_t count = st.count, score = st.score;
@@ -760,12 +897,17 @@ class Planner {
   // unblock each other instead of the first ones that happen to come up.
   SweepPlan build_sweep(const std::vector<GateRec> &pending, const std::vector<uint64_t> &alg,
                         std::vector<GateRec> *rest, std::vector<uint64_t> *rest_alg,
-                        std::vector<uint32_t> *rest_w) {
+                        std::vector<uint32_t> *rest_w, const std::vector<int> *forced_sel = nullptr) {
     SweepPlan sp;
     const uint64_t always = (1ull << lane_low_) - 1;
     std::vector<int> sel, lanehi, regs, waves;
-    select_tile_bits(pending, &sel);
-    assign_bits(sel, &lanehi, &regs, &waves);
+    if (forced_sel) sel = *forced_sel;
+    else select_tile_bits(pending, &sel);
+    if (!assign_bits(sel, &lanehi, &regs, &waves) && forced_sel) {     // (a tile the search proposed does not fit after all)
+      sel.clear(); lanehi.clear(); regs.clear(); waves.clear();
+      select_tile_bits(pending, &sel);
+      assign_bits(sel, &lanehi, &regs, &waves);
+    }
     uint64_t regmask = mask_of(regs);
     uint64_t lanemask = always | mask_of(lanehi);
     std::vector<uint8_t> flags(pending.size(), 0);
@@ -1560,7 +1702,34 @@ inline PlanResult plan_best(const std::vector<GateRec> &queue, int nloc, uint64_
       }
       if (best_n <= 1 && !best_far) break;
     }
-    return Planner(nloc, shard, bw, max_rb, split_lanes, best_wb, allow_relayout, keep_ghosts).plan(queue);
+    Planner chosen(nloc, shard, bw, max_rb, split_lanes, best_wb, allow_relayout, keep_ghosts);
+    // one sweep less?  Worth a search only where a sweep costs more than the search: budget = the gate visits that fit
+    // into ~3/4 of one sweep's HBM time (2 x state bytes at 5.5 TB/s, ~2.5 ns per gate visit); QH_PLAN_SEARCH=0 switches
+    // it off, QH_PLAN_SEARCH_STEPS pins the budget
+    uint64_t dense_bits = 0;
+    for (const GateRec &q : queue) if (q.tgt >= 0 && q.tgt < nloc && !plan_diag(q.g, q.tgt)) dense_bits |= 1ull << q.tgt;
+    const int lane_low = bw == 128 ? 3 : 4;
+    const int cap = (kLaneBits - lane_low) + std::min({max_rb, max_reg_bits(bw), nloc - kLaneBits}) + best_wb;
+    const bool room = best_n >= 3 && popc(dense_bits >> lane_low) <= (int)(best_n - 1) * cap;   // every qubit visited at least once
+    if (room && env_flag("QH_PLAN_SEARCH", true) && !getenv("QH_FORCE_TILES")) {
+      const double sweep_us = 2.0 * (double)(bw == 128 ? 16 : 8) * (double)(1ull << nloc) / 5.5e6;
+      uint64_t budget = std::min<uint64_t>((uint64_t)(sweep_us * 0.75 * 400.0), 8000000);      // at most ~20 ms
+      if (const char *e = getenv("QH_PLAN_SEARCH_STEPS")) budget = strtoull(e, nullptr, 10);
+      if (budget >= 20000) {
+        std::vector<uint64_t> greedy;
+        size_t n = 0;
+        bool far = false;
+        Planner(nloc, shard, bw, max_rb, split_lanes, best_wb, allow_relayout, keep_ghosts).skeleton(queue, &n, &far, &greedy);
+        std::vector<std::vector<int>> tiles;
+        if (Planner(nloc, shard, bw, max_rb, split_lanes, best_wb, allow_relayout, keep_ghosts).search_tiles(queue, greedy, budget, &tiles)) {
+          Planner forced(nloc, shard, bw, max_rb, split_lanes, best_wb, allow_relayout, keep_ghosts);
+          forced.set_tiles(tiles);
+          PlanResult pr = forced.plan(queue);
+          if (pr.sweeps.size() < best_n && !plan_has_far_tile(pr)) return pr;     // (the model ignores relabelling: check)
+        }
+      }
+    }
+    return chosen.plan(queue);
   }
   PlanResult best;
   bool have = false, best_far = false;

@@ -227,3 +227,34 @@ def test_every_rank_plans_the_same_geometry(oracle, monkeypatch, env):
       got[shard << nloc: (shard + 1) << nloc] = part
     err = float(np.max(np.abs(got - want)))
     assert err < 1e-11, (env, case, n, gshard, err)
+
+
+def test_tile_search_saves_a_sweep_and_keeps_the_amplitudes(oracle, monkeypatch):
+  """planner.h search_tiles: for layered circuits the greedy tile choice is not the best one; a budgeted local search
+  (deterministic, counted in gate visits) looks for one sweep less.  BASELINE config 3 (30 qubits, depth 20, seed 0):
+  5 -> 4 sweeps; the plans it produces must of course still compute the circuit (here at 16 qubits, through NumPy)."""
+  from tests.test_planner_cpu import _plan
+  ops, g8 = workloads.supremacy_stream(30, 20, seed=0).arrays()
+  monkeypatch.setenv('QH_PLAN_SEARCH', '0')
+  greedy = len(_plan(30, ops, g8)['sweeps'])
+  monkeypatch.setenv('QH_PLAN_SEARCH', '1')
+  searched = _plan(30, ops, g8)
+  assert greedy == 5 and len(searched['sweeps']) == 4
+  assert sum(s['gates'] for s in searched['sweeps']) + searched['noop_gates'] == len(ops)
+  monkeypatch.setenv('QH_PLAN_SEARCH_STEPS', '4000000')      # (small states get no budget by default: a sweep is cheap there)
+  rng = np.random.default_rng(16)
+  for n, seed in ((16, 0), (17, 3), (15, 1)):
+    sops, sg = workloads.supremacy_stream(n, 20, seed=seed).arrays()
+    stream = [([] if c == NO_CTL else [int(c)], int(t), g.view(np.complex128).copy()) for (c, t), g in zip(sops, sg)]
+    psi = rng.standard_normal(1 << n) + 1j * rng.standard_normal(1 << n)
+    psi = (psi / np.linalg.norm(psi)).astype(np.complex128)
+    want = psi.copy()
+    oracle.run_stream(want, n, sops, sg)
+    monkeypatch.setenv('QH_PLAN_SEARCH', '0')
+    base = _planned(n, n, 0, stream)
+    monkeypatch.setenv('QH_PLAN_SEARCH', '1')
+    sweeps = _planned(n, n, 0, stream)
+    assert len(sweeps) <= len(base)
+    got = psi.copy()
+    plan_interp.run_plan(got, sweeps, n)
+    assert np.max(np.abs(got - want)) < 1e-11, (n, seed, len(base), len(sweeps))
