@@ -1347,8 +1347,8 @@ int do_exchange(qh_state_s *h, const std::vector<qh::BlockMove> &moves, int base
     io.slab_done.assign(K, all_done);
   }
   // 3. geometry of the rounds.  Two ways to move a round: DIRECT -- the blocks are contiguous runs of the shard,
-  // sent from where they lie and copied home from the staging area -- when the low free bits give runs of at
-  // least 4 MiB; PACKED -- a gather kernel packs each peer's amplitudes of the round into the staging area, a
+  // sent from where they lie and copied home from the staging area -- when the low free bits give runs of a
+  // whole chunk (or 16 MiB); PACKED -- a gather kernel packs each peer's amplitudes of the round into the staging area, a
   // scatter kernel puts the received ones in place -- whatever the layout (after relayout sweeps the blocks'
   // bits may sit anywhere above the 128-byte line).
   const uint64_t free_mask = h->local_mask() & ~blockbits & ~slab_mask;
@@ -1358,7 +1358,7 @@ int do_exchange(qh_state_s *h, const std::vector<qh::BlockMove> &moves, int base
   int want_bits = 0;
   while ((2ull << want_bits) <= chunk_amps && want_bits + 1 <= nfree) want_bits++;
   const int force = env_int("QH_EXCHANGE_PACK", -1);      // tests: 1 = always packed, 0 = never
-  const bool packed = force >= 0 ? force != 0 : run_bits < std::min(want_bits, 18);
+  const bool packed = force >= 0 ? force != 0 : run_bits < std::min(want_bits, 20);   // direct: whole chunks, or runs of >= 16 MiB
   const int chunk_bits = packed ? want_bits : std::min(want_bits, run_bits);
   const uint64_t n = 1ull << chunk_bits;                       // amplitudes per peer and round
   const uint64_t nchunks = 1ull << (nfree - chunk_bits);

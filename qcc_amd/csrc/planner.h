@@ -372,24 +372,45 @@ class Planner {
     std::vector<uint64_t> alg;
     uint64_t noops = 0;
     prepare(queue, &pending, &alg, &noops);
+    // The search runs on CANONICAL bit numbers -- index bits above the 128-byte line renumbered in the order the
+    // queue first uses them -- so that the same circuit gets the same walk, and the same answer, whatever layout
+    // earlier relayout sweeps have left the state in (a loop over one circuit sees a different layout every step).
+    const uint64_t always = (1ull << lane_low_) - 1;
+    int canon[64], back[64], ncanon = lane_low_;
+    for (int b = 0; b < 64; ++b) canon[b] = b < lane_low_ ? b : -1;
+    auto canon_mask = [&](uint64_t m) {
+      uint64_t o = 0;
+      for (uint64_t t = m; t; t &= t - 1) {
+        const int b = __builtin_ctzll(t);
+        if (canon[b] < 0) canon[b] = ncanon++;
+        o |= 1ull << canon[b];
+      }
+      return o;
+    };
     std::vector<PassRec> rec0(pending.size());
     uint64_t dense_used = 0;
     for (size_t i = 0; i < pending.size(); ++i) {
       const GateRec &r = pending[i];
       const bool diag = plan_diag(r.g, r.tgt);
-      const uint64_t tb = (r.tgt >= 0) ? (1ull << r.tgt) : 0;
-      rec0[i] = PassRec{diag ? 0 : tb, r.ctl_mask | r.neg_mask | (diag ? tb : 0), 1, r.tgt};
+      const uint64_t tb = canon_mask((r.tgt >= 0) ? (1ull << r.tgt) : 0);
+      const uint64_t cb = canon_mask((r.ctl_mask | r.neg_mask) & ((1ull << nloc_) - 1));
+      rec0[i] = PassRec{diag ? 0 : tb, cb | (diag ? tb : 0), 1, tb ? __builtin_ctzll(tb) : -1};
       if (!diag) dense_used |= tb;
     }
-    const uint64_t always = (1ull << lane_low_) - 1;
+    for (int b = 0; b < 64; ++b) if (canon[b] >= 0) back[canon[b]] = b;
     const uint64_t movable = dense_used & ~always;
     const int cap = lane_hi_ + rb_cap_ + max_wave_;
     if ((size_t)popc(movable) > K * (size_t)cap) return false;       // not even room to visit every qubit once
     uint64_t rng = 0x9e3779b97f4a7c15ull;
     auto rnd = [&](uint32_t n) { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return (uint32_t)((rng >> 11) % n); };
     auto pick_bit = [&](uint64_t m) { int k = (int)rnd((uint32_t)popc(m)); while (k--) m &= m - 1; return __builtin_ctzll(m); };
-    std::vector<uint64_t> cur(greedy_tiles.begin(), greedy_tiles.begin() + (long)K), best_tiles;
-    for (uint64_t &t : cur) t &= ~always;
+    std::vector<uint64_t> cur, best_tiles;
+    for (size_t k = 0; k < K; ++k) {
+      uint64_t t = 0;
+      for (uint64_t m = greedy_tiles[k] & ~always; m; m &= m - 1)
+        if (canon[__builtin_ctzll(m)] >= 0) t |= 1ull << canon[__builtin_ctzll(m)];
+      cur.push_back(t & movable);
+    }
     std::vector<SearchSweep> st(K), trial(K);
     uint64_t steps = 0;
     auto eval_from = [&](const std::vector<uint64_t> &tiles, size_t from, std::vector<SearchSweep> *out) {
@@ -415,7 +436,7 @@ class Planner {
         for (uint64_t t = s; t; t &= t - 1) if (st[i].cnt[__builtin_ctzll(t)] <= m + slack) pool |= t & -t;
         ns &= ~(1ull << pick_bit(pool));
       }
-      if (ns == s || popc(ns) > cap || !tile_fits(ns)) continue;
+      if (ns == s || popc(ns) > cap) continue;       // (whether the positions suit a tile is checked when the plan is built)
       for (size_t k = 0; k < i; ++k) trial[k].rest.clear();          // (prefix unchanged: evaluated from sweep i on)
       std::vector<uint64_t> cand = cur;
       cand[i] = ns;
@@ -444,7 +465,8 @@ class Planner {
     tiles_out->clear();
     for (uint64_t t : best_tiles) {
       std::vector<int> b;
-      for (; t; t &= t - 1) b.push_back(__builtin_ctzll(t));
+      for (; t; t &= t - 1) b.push_back(back[__builtin_ctzll(t)]);
+      std::sort(b.begin(), b.end());
       tiles_out->push_back(b);
     }
     return true;
@@ -1703,9 +1725,11 @@ inline PlanResult plan_best(const std::vector<GateRec> &queue, int nloc, uint64_
       if (best_n <= 1 && !best_far) break;
     }
     Planner chosen(nloc, shard, bw, max_rb, split_lanes, best_wb, allow_relayout, keep_ghosts);
-    // one sweep less?  Worth a search only where a sweep costs more than the search: budget = the gate visits that fit
-    // into ~3/4 of one sweep's HBM time (2 x state bytes at 5.5 TB/s, ~2.5 ns per gate visit); QH_PLAN_SEARCH=0 switches
-    // it off, QH_PLAN_SEARCH_STEPS pins the budget
+    // one sweep less?  Worth a search only where a sweep costs about what the search does: budget = the gate visits
+    // that fit into ~1.6 sweep times (2 x state bytes at 5.5 TB/s, ~2.5 ns per gate visit: 4 M visits = ~10 ms of host
+    // time for a 16-GiB state, hidden behind the GPU whenever circuits are submitted back to back, paid once per
+    // circuit with the plan cache on; eight supremacy-30 instances: 5 6 6 6 7 7 6 6 sweeps greedy, 4 6 5 5 6 6 5 5 with
+    // the search).  QH_PLAN_SEARCH=0 switches it off, QH_PLAN_SEARCH_STEPS pins the budget.
     uint64_t dense_bits = 0;
     for (const GateRec &q : queue) if (q.tgt >= 0 && q.tgt < nloc && !plan_diag(q.g, q.tgt)) dense_bits |= 1ull << q.tgt;
     const int lane_low = bw == 128 ? 3 : 4;
@@ -1713,7 +1737,7 @@ inline PlanResult plan_best(const std::vector<GateRec> &queue, int nloc, uint64_
     const bool room = best_n >= 3 && popc(dense_bits >> lane_low) <= (int)(best_n - 1) * cap;   // every qubit visited at least once
     if (room && env_flag("QH_PLAN_SEARCH", true) && !getenv("QH_FORCE_TILES")) {
       const double sweep_us = 2.0 * (double)(bw == 128 ? 16 : 8) * (double)(1ull << nloc) / 5.5e6;
-      uint64_t budget = std::min<uint64_t>((uint64_t)(sweep_us * 0.75 * 400.0), 8000000);      // at most ~20 ms
+      uint64_t budget = std::min<uint64_t>((uint64_t)(sweep_us * 650.0), 8000000);      // ~1.6 sweep times of host work, at most ~20 ms
       if (const char *e = getenv("QH_PLAN_SEARCH_STEPS")) budget = strtoull(e, nullptr, 10);
       if (budget >= 20000) {
         std::vector<uint64_t> greedy;

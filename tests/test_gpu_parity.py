@@ -56,6 +56,25 @@ def test_golden_single_and_controlled(golden_dir, fusion):
 
 
 @pytest.mark.parametrize('fusion', FUSIONS)
+def test_golden_every_ordered_pair_n9_n10(golden_dir, fusion):
+  """G4 of SURVEY 8(c) for every ordered (ctl, tgt) at 9 and 10 qubits against what the reference's applyc computed
+  (tests/golden/g4_pairs_n9_n10.npz: 16 probe inner products per case, a few outputs in full)."""
+  g = np.load(os.path.join(golden_dir, 'g4_pairs_n9_n10.npz'))
+  for n in (9, 10):
+    probes = g[f'probes_n{n}']
+    full = {str(k): v for k, v in zip(g[f'full_names_n{n}'], g[f'full_n{n}'])}
+    with device.DeviceState(n, 128, fusion=fusion) as st:
+      for name, gate, proj in zip(g[f'names_n{n}'], g[f'gates_n{n}'], g[f'proj_n{n}']):
+        _, c, t = str(name).split(':')
+        st.upload(g[f'psi0_n{n}'])
+        st.applyc(gate, int(c), int(t))
+        got = st.download()
+        assert np.max(np.abs(probes.conj() @ got - proj)) <= 1e-13, (n, name)
+        if str(name) in full:
+          assert np.max(np.abs(got - full[str(name)])) <= TOL, (n, name)
+
+
+@pytest.mark.parametrize('fusion', FUSIONS)
 def test_golden_complex64(golden_dir, fusion):
   g = np.load(os.path.join(golden_dir, 'g7_c64.npz'))
   n = int(g['nbits'])

@@ -44,6 +44,24 @@ def test_controlled_every_pair(oracle, golden_dir, fname):
     assert np.max(np.abs(psi - out)) <= TOL128, name
 
 
+@pytest.mark.parametrize('n', [9, 10])
+def test_controlled_every_pair_n9_n10(oracle, golden_dir, n):
+  """G4 for EVERY ordered (ctl, tgt) at 9 and 10 qubits (tools/make_golden_r3.py: the reference's own applyc; each
+  output stored as 16 inner products with stored probe vectors, plus a few outputs in full)."""
+  g = _load(golden_dir, 'g4_pairs_n9_n10.npz')
+  names = [str(s) for s in g[f'names_n{n}']]
+  assert len(names) == 4 * n * (n - 1)
+  full = {str(k): v for k, v in zip(g[f'full_names_n{n}'], g[f'full_n{n}'])}
+  probes = g[f'probes_n{n}']
+  for name, gate, proj in zip(names, g[f'gates_n{n}'], g[f'proj_n{n}']):
+    _, c, t = name.split(':')
+    psi = g[f'psi0_n{n}'].copy()
+    oracle.applyc(psi, gate, n, int(c), int(t))
+    assert np.max(np.abs(probes.conj() @ psi - proj)) <= 4e-15, name
+    if name in full:
+      assert np.max(np.abs(psi - full[name])) <= TOL128, name
+
+
 def test_complex64(oracle, golden_dir):
   g = _load(golden_dir, 'g7_c64.npz')
   n = int(g['nbits'])
