@@ -36,6 +36,10 @@ struct GateRec {
   // rank-dependent phase is 1).  Ghosts stay in the gate list so that every rank plans the same sweeps, tiles and
   // layouts (an exchange needs the ranks to agree on where every index bit lives); they emit no arithmetic.
   uint8_t ghost = 0, variant = 0;
+  // planner-internal: a diagonal gate on a shard bit, re-expressed on one of its local control bits, whose factor is
+  // zero on SOME rank (a projector fed through apply1): "phase factor or dense 2x2" would then be decided differently
+  // from rank to rank, so every rank takes the dense path
+  uint8_t force_dense = 0;
 };
 
 // The boundary only ever sees the four matrix entries: classify by
@@ -50,6 +54,7 @@ inline bool is_one(double re, double im) { return re == 1.0 && im == 0.0; }
 inline bool plan_diag(const double g[8], int tgt) {
   return is_diag(g) && (tgt < 0 || !(g[0] == 0.0 && g[1] == 0.0));
 }
+inline bool plan_diag(const GateRec &r) { return !r.force_dense && plan_diag(r.g, r.tgt); }
 
 constexpr int kLaneBits = 6;   // wavefront = 64 lanes
 constexpr int kLaneLow = 3;    // complex128: lane bits 0..2 are ALWAYS index bits 0..2 (8 x 16 B = one 128-byte line);
@@ -274,6 +279,7 @@ class Planner {
           const int c = __builtin_ctzll(r.ctl_mask);
           r.ctl_mask &= ~(1ull << c);
           r.tgt = c;
+          r.force_dense = ((r.g[0] == 0.0 && r.g[1] == 0.0) || (r.g[6] == 0.0 && r.g[7] == 0.0)) ? 1 : 0;
           r.g[0] = 1; r.g[1] = 0; r.g[6] = fr; r.g[7] = fi;
         } else {
           r.tgt = -1;
@@ -391,7 +397,7 @@ class Planner {
     uint64_t dense_used = 0;
     for (size_t i = 0; i < pending.size(); ++i) {
       const GateRec &r = pending[i];
-      const bool diag = plan_diag(r.g, r.tgt);
+      const bool diag = plan_diag(r);
       const uint64_t tb = canon_mask((r.tgt >= 0) ? (1ull << r.tgt) : 0);
       const uint64_t cb = canon_mask((r.ctl_mask | r.neg_mask) & ((1ull << nloc_) - 1));
       rec0[i] = PassRec{diag ? 0 : tb, cb | (diag ? tb : 0), 1, tb ? __builtin_ctzll(tb) : -1};
@@ -629,7 +635,7 @@ class Planner {
       // control bits are executed here instead.
       // (a diagonal gate that touches a shard bit has rank-dependent entries: every rank takes the cautious branch)
       const bool singular = r.variant || (r.g[0] == 0.0 && r.g[1] == 0.0) || (r.g[6] == 0.0 && r.g[7] == 0.0);
-      if (plan_diag(r.g, r.tgt) && c && (singular || popc((r.neg_mask ^ c) & (r.ctl_mask | r.neg_mask)) > 3)) {
+      if (plan_diag(r) && c && (singular || popc((r.neg_mask ^ c) & (r.ctl_mask | r.neg_mask)) > 3)) {
         for (uint64_t t = c; t; t &= t - 1) {
           const int b = __builtin_ctzll(t);
           emit_x(b);
@@ -742,7 +748,7 @@ class Planner {
     const size_t n = std::min(window, pending.size());
     for (size_t i = 0; i < n; ++i) {
       const GateRec &r = pending[i];
-      const bool diag = plan_diag(r.g, r.tgt);
+      const bool diag = plan_diag(r);
       const uint64_t tb = (r.tgt >= 0) ? (1ull << r.tgt) : 0;
       const uint64_t dense_bits = diag ? 0 : tb;
       const uint64_t diag_bits = r.ctl_mask | r.neg_mask | (diag ? tb : 0);
@@ -881,7 +887,7 @@ class Planner {
     uint64_t seen = 0;
     for (size_t i = 0; i < window; ++i) {
       const GateRec &r = pending[i];
-      const bool diag = plan_diag(r.g, r.tgt);
+      const bool diag = plan_diag(r);
       const uint64_t tb = (r.tgt >= 0) ? (1ull << r.tgt) : 0;
       rec[i] = PassRec{diag ? 0 : tb, r.ctl_mask | r.neg_mask | (diag ? tb : 0), (uint32_t)(diag ? 1 : dense_weight_), r.tgt};
       if (!diag && r.tgt >= lane_low_ && !((seen >> r.tgt) & 1ull)) {
@@ -941,11 +947,11 @@ class Planner {
     if (defer_diag_) {
       uint64_t future = 0, later_targets = 0;
       for (size_t i = 0; i < pending.size(); ++i)
-        if (!flags[i] && !plan_diag(pending[i].g, pending[i].tgt) && pending[i].tgt >= 0) future |= 1ull << pending[i].tgt;
+        if (!flags[i] && !plan_diag(pending[i]) && pending[i].tgt >= 0) future |= 1ull << pending[i].tgt;
       for (size_t i = pending.size(); i-- > 0;) {
         if (!flags[i]) continue;
         const GateRec &r = pending[i];
-        if (!plan_diag(r.g, r.tgt)) { later_targets |= 1ull << r.tgt; continue; }
+        if (!plan_diag(r)) { later_targets |= 1ull << r.tgt; continue; }
         const uint64_t bits = r.ctl_mask | r.neg_mask | (r.tgt >= 0 ? (1ull << r.tgt) : 0);
         if (!(bits & later_targets) && (bits & future)) flags[i] = 0;
       }
@@ -955,7 +961,7 @@ class Planner {
     for (size_t i = 0; i < pending.size(); ++i) {
       if (flags[i]) {
         taken.push_back(&pending[i]);
-        if (!plan_diag(pending[i].g, pending[i].tgt)) any_dense = true;
+        if (!plan_diag(pending[i])) any_dense = true;
         sp.gates += weight_[i];
         sp.alg_bytes += alg[i];
       } else {
@@ -969,7 +975,7 @@ class Planner {
       rest->erase(rest->begin());
       rest_alg->erase(rest_alg->begin());
       rest_w->erase(rest_w->begin());
-      if (!plan_diag(pending[0].g, pending[0].tgt) && !((lanemask >> pending[0].tgt) & 1ull)) {
+      if (!plan_diag(pending[0]) && !((lanemask >> pending[0].tgt) & 1ull)) {
         regs.assign(1, pending[0].tgt);
         waves.clear();
         regmask = 1ull << pending[0].tgt;
@@ -985,7 +991,7 @@ class Planner {
       std::vector<int> cnt(64, 0);
       int ndense = 0;
       for (const GateRec *r : taken)
-        if (!plan_diag(r->g, r->tgt) && r->tgt >= 0) { cnt[r->tgt]++; ndense++; }
+        if (!plan_diag(*r) && r->tgt >= 0) { cnt[r->tgt]++; ndense++; }
       if (ndense >= 16) {
         for (int iter = 0; iter < lane_hi_; ++iter) {
           int bl = -1, br = -1, gain = 0;
@@ -1011,7 +1017,7 @@ class Planner {
     {
       uint64_t used = 0;
       for (const GateRec *r : taken)
-        if (!plan_diag(r->g, r->tgt) && r->tgt >= 0) used |= 1ull << r->tgt;
+        if (!plan_diag(*r) && r->tgt >= 0) used |= 1ull << r->tgt;
       std::vector<int> keep;
       for (int p : regs) if ((used >> p) & 1ull) keep.push_back(p);
       regs.swap(keep);
@@ -1030,7 +1036,7 @@ class Planner {
     uint64_t common = ~0ull;
     for (const GateRec *r : taken) {
       uint64_t req = r->ctl_mask;
-      if (plan_diag(r->g, r->tgt) && r->tgt >= 0 && is_one(r->g[0], r->g[1])) req |= 1ull << r->tgt;
+      if (plan_diag(*r) && r->tgt >= 0 && is_one(r->g[0], r->g[1]) && !r->variant) req |= 1ull << r->tgt;   // (a variant gate's entries differ between ranks)
       common &= req;
     }
     regmask = 0;
@@ -1165,7 +1171,7 @@ class Planner {
       std::vector<int> cand;
       for (size_t i = 0; i < taken.size(); ++i) {
         const GateRec *r = taken[i];
-        if (plan_diag(r->g, r->tgt) || (r->ctl_mask & ~sp->fixed_ones) || r->neg_mask || r->variant) continue;
+        if (plan_diag(*r) || (r->ctl_mask & ~sp->fixed_ones) || r->neg_mask || r->variant) continue;
         last = (int)i;
         if (butterflies_ && butterfly_variant(r->g) >= 0) cand.push_back((int)i);
       }
@@ -1251,7 +1257,7 @@ class Planner {
       for (int r = 0; r < geom.rb; ++r) {
         size_t next = taken.size() + 1;
         for (size_t j = gi_now + 1; j < taken.size(); ++j)
-          if (!plan_diag(taken[j]->g, taken[j]->tgt) && taken[j]->tgt == geom.regpos[r]) { next = j; break; }
+          if (!plan_diag(*taken[j]) && taken[j]->tgt == geom.regpos[r]) { next = j; break; }
         // ties: a register no exchange has touched yet (its exchange can then be undone, or left, on its own)
         bool used = false, best_used = false;
         for (const Swap &w : swaps) { used |= w.r == r; best_used |= w.r == best; }
@@ -1285,7 +1291,7 @@ class Planner {
     };
     for (size_t gi = 0; gi < taken.size(); ++gi) {
       const GateRec *r = taken[gi];
-      const bool diag = plan_diag(r->g, r->tgt);
+      const bool diag = plan_diag(*r);
       if (diag && r->ghost) continue;           // (no phase here; diagonal gates never move the layout)
       if (!diag) {
         // a target that lives in the wave id comes into a register bit first: the phases

@@ -134,6 +134,8 @@ class ShardedState:
     self._native_chunk = int(os.environ.get('QCC_EXCHANGE_CHUNK_AMPS', '0')) or self.chunk
     if self.world > 1 or os.environ.get('QCC_EXCHANGE') == 'native':
       self._init_native_exchange()
+    elif self._hip and self.buf is None:
+      self.exchange_path = 'none (one rank: nothing to exchange)'
     if self._hip and self.buf is None and not self._native and self.world > 1:
       raise RuntimeError(f'the engine-native exchange could not be set up ({self.exchange_path}); '
                          'QCC_EXCHANGE=torch selects the torch.distributed double explicitly')

@@ -14,7 +14,8 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tests import oracle_lib, plan_interp  # noqa: E402
-from tests.test_planner_semantics_cpu import ENVS, _oracle_apply, _planned, _stream  # noqa: E402
+from tests.test_planner_semantics_cpu import (ENVS, GEOMETRY_KEYS, _oracle_apply, _planned, _shard_variant_stream,  # noqa: E402
+                                               _stream)
 
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 budget = float(sys.argv[2]) if len(sys.argv) > 2 else 60.0
@@ -28,8 +29,13 @@ while time.time() - t0 < budget:
   os.environ.update(env)
   rng = np.random.default_rng(seed * 7919 + cases)
   n = int(rng.integers(10, 17))
-  gshard = int(rng.integers(0, 3)) if rng.random() < 0.3 else 0
-  stream = _stream(rng, n, int(rng.integers(10, 400)), gshard)
+  gshard = int(rng.integers(0, 4)) if rng.random() < 0.4 else 0
+  if cases % 2 and os.environ.get('QH_PLAN_SEARCH_STEPS') is None:
+    os.environ['QH_PLAN_SEARCH_STEPS'] = '300000'        # the tile search too (small states get no budget by default)
+  n = max(n, 10 + gshard)
+  # sharded cases: half of them with plenty of rank-dependent gates (ghosts on some ranks, planner.h)
+  stream = (_shard_variant_stream(rng, n, int(rng.integers(10, 300)), gshard) if gshard and rng.random() < 0.5
+            else _stream(rng, n, int(rng.integers(10, 400)), gshard))
   psi = rng.standard_normal(1 << n) + 1j * rng.standard_normal(1 << n)
   psi = (psi / np.linalg.norm(psi)).astype(np.complex128)
   want = psi.copy()
@@ -37,9 +43,14 @@ while time.time() - t0 < budget:
   nloc = n - gshard
   got = np.empty_like(psi)
   try:
+    geom0 = None
     for shard in range(1 << gshard):
       part = psi[shard << nloc: (shard + 1) << nloc].copy()
-      plan_interp.run_plan(part, _planned(n, nloc, shard, stream, bw=int(os.environ.get('FUZZ_BW', 128 if cases % 3 else 64))), nloc, shard)
+      sweeps = _planned(n, nloc, shard, stream, bw=int(os.environ.get('FUZZ_BW', 128 if cases % 3 else 64)))
+      geom = [[(k, sp[k]) for k in GEOMETRY_KEYS] for sp in sweeps]
+      geom0 = geom if geom0 is None else geom0
+      assert geom == geom0, f'shard {shard} plans another geometry than shard 0'
+      plan_interp.run_plan(part, sweeps, nloc, shard)
       got[shard << nloc: (shard + 1) << nloc] = part
     err = float(np.max(np.abs(got - want)))
   except AssertionError as e:
