@@ -565,6 +565,7 @@ class Planner {
   int lane_valu_ = env_int("QH_LANE_VALU", 1);          // 0 never, 1 by cost model (choose_lane_paths), 2 always (tests)
   bool defer_diag_ = env_flag("QH_DEFER_DIAG", true);   // see build_sweep
   bool lookahead_ = env_flag("QH_RELAYOUT_AHEAD", true); // see finish_relayout
+  bool relayout_contig_ = env_flag("QH_RELAYOUT_CONTIG", false);   // see want_relayout
   std::vector<uint64_t> alg_override_;
   std::vector<uint32_t> weight_;  // reference gate applications each pending record stands for
   std::vector<std::vector<int>> tiles_ = parse_tiles(getenv("QH_FORCE_TILES"));   // "3,6,7;12,13" = tile bits of sweep 0; sweep 1 (experiments)
@@ -1424,7 +1425,7 @@ class Planner {
     // slower store geometry -- 7.1 vs 6.75 ms on sweep 2 of the QFT -- and undoing wins)
     // A RELAYOUT sweep stores the tile contiguously into the second buffer whatever its bits are
     // now: neither kind of exchange is undone (see relayout()).
-    if (want_relayout(*sp)) {
+    if (want_relayout(*sp, !swaps.empty())) {
       sp->relayout = true;      // (dest_pos: plan() -> finish_relayout, once the next sweep's targets are known)
     } else if (store_swapped_ && sp->contiguous()) {
       if (!undo_lane_swaps()) restore_layout();
@@ -1454,8 +1455,9 @@ class Planner {
   // same tiles (tools/membench/oopsweep): scattered load + CONTIGUOUS store into a second buffer
   // runs 15-20% faster than the in-place sweep, so a sweep that touches every amplitude anyway
   // may as well leave its tile bits on the low positions -- where they stay for the next flush.
-  bool want_relayout(const SweepPlan &sp) const {
+  bool want_relayout(const SweepPlan &sp, bool has_swaps = false) const {
     if (!relayout_ || sp.fixed_ones) return false;      // (a sweep that skips amplitudes cannot move the rest)
+    if (has_swaps && relayout_contig_) return true;     // a contiguous tile with layout exchanges to undo: store them as they are
     const int low = sp.lane_low;
     for (int k = 0; k < sp.nlanehi(); ++k) if (sp.lanehi[k] != low + k) return true;
     for (int k = 0; k < sp.rb; ++k) if (sp.regpos[k] != kLaneBits + k) return true;
