@@ -14,15 +14,16 @@ build() {  # build <tag> <load bits> <store bits>
   (cd $d && hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -o $V/libqcc_$tag.so qcc_amd/csrc/engine.hip qcc_amd/csrc/libq_facade.cc 2>&1 | grep -v "warning: ignoring\|^$" | head -5)
   echo "built $tag: loads '$ld' stores '$st'"
 }
+# round-3 batch 1 (nt/plain/sc0/sc1 one side at a time): stores "sc1 nt" -2.3 % on the QFT, everything else within 1 %
 build nt_nt "nt" "nt" &
-build plain_nt "" "nt" &
-build nt_plain "nt" "" &
-wait
-build sc1nt_nt "sc1 nt" "nt" &
 build nt_sc1nt "nt" "sc1 nt" &
-build nt_sc01nt "nt" "sc0 sc1 nt" &
+build sc1nt_sc1nt "sc1 nt" "sc1 nt" &
 wait
-build sc0nt_sc0nt "sc0 nt" "sc0 nt" &
-build plain_plain "" "" &
+build sc01nt_sc1nt "sc0 sc1 nt" "sc1 nt" &
+build nt_sc1 "nt" "sc1" &
+build sc0nt_sc1nt "sc0 nt" "sc1 nt" &
+wait
+build plain_sc1nt "" "sc1 nt" &
+build sc1nt_sc01nt "sc1 nt" "sc0 sc1 nt" &
 wait
 ls -la $V
