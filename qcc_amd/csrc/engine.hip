@@ -290,7 +290,9 @@ bool alloc_second_buffer(qh_state_s *h) {
   if (h->d_alt) return true;
   const size_t bytes = (size_t)h->amp_bytes() << h->nloc;
   size_t fr = 0, total = 0;
-  if (hipMemGetInfo(&fr, &total) == hipSuccess && fr > bytes + (bytes >> 5) + (3ull << 29) &&
+  // (a communicator of several ranks will want its staging halves too: up to 4 x (P-1) x chunk amplitudes)
+  const size_t reserve = (bytes >> 5) + (3ull << 29) + ((h->comm && h->comm->nranks > 1) ? (4ull << 30) : 0);
+  if (hipMemGetInfo(&fr, &total) == hipSuccess && fr > bytes + reserve &&
       hipMalloc(&h->d_alt, bytes) == hipSuccess)
     return true;
   (void)hipGetLastError();

@@ -50,6 +50,7 @@ except Exception:  # pylint: disable=broad-except
 _SNAPSHOT_LIMIT_BITS = 31  # above this a full host snapshot is refused (>= 32 GiB)
 _MEASURE_SNAPSHOT_BITS = 26  # measure_bit returns the real State up to here (1 GiB), a lazy handle above
 _ALIAS_LIMIT_BITS = 26     # alias_psi: registers up to this size live in host-mapped memory
+_NO_CTL = -(2 ** 31)       # "no control" in a gate stream (include/qcc_hip.h QH_NO_CTL)
 
 
 def _dump_flags_set():
@@ -144,11 +145,16 @@ class qc:
         # gate arrives -- the reference np.kron's on the host at every call
         # (circuit.py:121-123).
         self._factors = []
-        self._is_product = True  # True until something non-trivial happens
+        self._product_flag = True  # (_is_product) True until something non-trivial happens
         self._host = None        # State snapshot (valid iff _host_ok)
         self._host_ok = False
         self._dev = None         # device state (valid iff _dev_ok)
         self._dev_ok = False
+        # eager gates wait HERE, as (control | NO_CTL, target) + matrix, until something reads the state: they then
+        # reach the engine through ONE native call (qh_apply_stream) instead of one FFI round trip per gate
+        # (ctypes + NumPy conversions cost ~25 us per gate, the reference's own Python overhead is 6.5 us: SURVEY 8a A5)
+        self._q_ops = []
+        self._q_gates = []
         if _dump_flags_set():
             self.eager = False
 
@@ -162,6 +168,18 @@ class qc:
 
     # ------------------------------------------------------------------ state plumbing
     @property
+    def _is_product(self):
+        """Still the tensor product of the pieces handed in?  (Asking submits the gates queued on the host side
+        first: whoever asks is about to read or rebuild the state.)"""
+        if self._q_ops:
+            self._drain()
+        return self._product_flag
+
+    @_is_product.setter
+    def _is_product(self, value):
+        self._product_flag = bool(value)
+
+    @property
     def nbits(self):
         return self._nbits
 
@@ -169,7 +187,38 @@ class qc:
         return tensor.tensor_width()
 
     def _ensure_device(self):
-        """Make the device copy authoritative-capable and current."""
+        """Make the device copy authoritative-capable and current (queued gates submitted)."""
+        dev = self._device_ready()
+        if self._q_ops:
+            self._drain()
+        return dev
+
+    def _drain(self):
+        """Hand the gates queued on the host side to the engine, in order."""
+        if not self._q_ops:
+            return
+        ops_, gs = self._q_ops, self._q_gates
+        self._q_ops, self._q_gates = [], []
+        dev = self._device_ready()
+        if hasattr(dev, 'run_stream'):
+            dev.run_stream(np.array(ops_, dtype=np.int32).reshape(-1, 2),
+                           np.array(gs, dtype=np.complex128).reshape(-1, 4).view(np.float64).reshape(-1, 8))
+        else:
+            for (c, t), g in zip(ops_, gs):
+                if c == _NO_CTL:
+                    dev.apply1(g, t)
+                else:
+                    dev.applyc(g, c, t)
+        self._gate_done()
+
+    def flush(self):
+        """Submit everything queued so far (host side and engine side) without waiting for it."""
+        if self._nbits:
+            dev = self._ensure_device()
+            if hasattr(dev, 'flush'):
+                dev.flush()
+
+    def _device_ready(self):
         if self._nbits == 0:
             raise ValueError('circuit has no qubits yet')
         if self._dev is not None and (self._dev.nbits != self._nbits or self._dev.bit_width != self._width()):
@@ -182,7 +231,7 @@ class qc:
             else:
                 self._dev = backend.make_device_state(self._nbits, self._width())
         if not self._dev_ok:
-            if self._is_product:
+            if self._product_flag:          # (the raw flag: queued gates run right after, on this very state)
                 self._dev.init_product(self._factors)
             else:
                 assert self._host_ok, 'no valid copy of the state'
@@ -199,6 +248,8 @@ class qc:
     def psi(self):
         if self._nbits == 0:
             return state.State(1.0)
+        if self._q_ops:
+            self._drain()
         if self._aliased():
             dev = self._ensure_device()
             dev.sync()
@@ -229,6 +280,8 @@ class qc:
 
     @psi.setter
     def psi(self, value):
+        if self._q_ops:
+            self._drain()
         host = value if isinstance(value, state.State) else state.State(value)
         if host.dtype != tensor.tensor_type():
             host = state.State(host)
@@ -347,7 +400,14 @@ class qc:
                 self.ir.single(name, idx, gate, val)
             if self.eager:
                 assert idx < self._nbits, 'Invalid qubit index'
-                self._ensure_device().apply1(np.asarray(gate).reshape(4), idx)
+                if self._aliased():
+                    self._ensure_device().apply1(np.asarray(gate).reshape(4), idx)
+                else:
+                    if idx < 0:
+                        raise ValueError(f'apply1: qubit {idx} out of range for {self._nbits} qubits')
+                    self._q_ops.append((_NO_CTL, int(idx)))
+                    self._q_gates.append(np.array(gate, dtype=np.complex128).reshape(4))
+                    continue
                 self._gate_done()
 
     def applyc(self, gate, ctl, idx, name=None, *, val=None):
@@ -361,8 +421,17 @@ class qc:
             self.ir.controlled(name, ctl_qubit, idx, gate, val)
         if self.eager:
             assert idx < self._nbits, 'Invalid qubit index'
-            self._ensure_device().applyc(np.asarray(gate).reshape(4), ctl_qubit, idx)
-            self._gate_done()
+            if self._aliased():
+                self._ensure_device().applyc(np.asarray(gate).reshape(4), ctl_qubit, idx)
+            else:
+                if idx < 0 or ctl_qubit >= self._nbits:
+                    raise ValueError(f'applyc: qubits ({ctl_qubit}, {idx}) out of range for {self._nbits} qubits')
+                if ctl_qubit == idx:
+                    raise ValueError(f'applyc: control == target (qubit {idx})')
+                self._q_ops.append((int(ctl_qubit), int(idx)))
+                self._q_gates.append(np.array(gate, dtype=np.complex128).reshape(4))
+            if self._aliased():
+                self._gate_done()
         self.x(ctl_qubit, by_0)
 
     def _gate_done(self):
@@ -438,12 +507,16 @@ class qc:
     # ------------------------------------------------------------------ readers / measurement
     def maxprob(self):
         """(bits, probability) of the likeliest basis state, reduced on the device."""
+        if self._q_ops:
+            self._drain()
         if not self._dev_ok:
             return self.psi.maxprob()
         idx, p = self._dev.argmax()
         return helper.val2bits(idx, self._nbits), p
 
     def ampl(self, *bits):
+        if self._q_ops:
+            self._drain()
         if not self._dev_ok:
             return self.psi.ampl(*bits)
         return self._dev.amplitude(helper.bits2val(bits))
@@ -609,10 +682,13 @@ class qc:
 
     def sync(self):
         """Wait for all queued device work (for timing)."""
+        if self._q_ops:
+            self._drain()
         if self._dev is not None:
             self._dev.sync()
 
     def close(self):
+        self._q_ops, self._q_gates = [], []
         if self._dev is not None:
             if not self._alias:
                 self._dev.close()

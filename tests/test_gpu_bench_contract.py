@@ -45,3 +45,25 @@ def test_bench_sharded_world_of_one():
   d = _run('--sharded', '--qubits', '22', '--steps', '2', '--warmup', '1', '--no-cpu-baseline', env={'QCC_EXCHANGE': 'native'})
   assert d['n_gpus'] == 1 and d['exchange_path'] == 'rccl' and d['exchanges_per_step'] == 0
   assert abs(d['norm2'] - 1) < 1e-10
+
+
+@pytest.mark.parametrize('ranks', [2, 4])
+def test_bench_multi_rank_launch_on_one_gpu(ranks):
+  """The driver's multi-GPU command line (python -m torch.distributed.run ... bench.py --gpus N), with the ranks sharing
+  the one GPU of the test box (gloo between them, the engine's exchange over the host-staged transport): the barrier /
+  MAX-over-ranks timing, one JSON line from rank 0, the exchange accounting, the norm."""
+  import socket
+  s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+  e = dict(os.environ)
+  e.update(QCC_DIST_BACKEND='gloo', QCC_PRELOAD_TORCH='1')
+  r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={ranks}', '--master-addr', '127.0.0.1',
+                      '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', str(ranks), '--qubits', '24', '--steps', '2',
+                      '--warmup', '1'], capture_output=True, text=True, timeout=900, cwd=ROOT, env=e)
+  assert r.returncode == 0, r.stderr[-3000:]
+  lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+  assert len(lines) == 1, r.stdout[-1000:]
+  d = json.loads(lines[0])
+  assert d['n_gpus'] == ranks and d['steps'] == 2 and d['scaling'] == 'weak' and d['exchange_path'] == 'host-staged'
+  assert d['exchanges_per_step'] >= 1 and d['xgmi_bytes_per_rank_per_step'] > 0
+  assert abs(d['norm2'] - 1) < 1e-10
+  assert abs(d['value'] - 300 * 2 * 2 ** (24 - 30) / (d['ms_per_step'] * 2e-3)) / d['value'] < 1e-6

@@ -25,6 +25,7 @@ def cpu_backend():
 
 
 def _trace_of(qc):
+  qc.flush()                 # eager gates queue on the host side until something reads the state (circuit.qc._drain)
   tr = qc._dev.trace
   ops_ = np.array([(-(2 ** 31) if c is None else c, t) for c, t, _ in tr], dtype=np.int64)
   gs = np.array([g for _, _, g in tr]).view(np.float64).reshape(-1, 8)
