@@ -251,10 +251,24 @@ __global__ __launch_bounds__(256) void k_norm2(const typename AmpT<R>::type *__r
                                                 uint64_t n, uint64_t mask, uint64_t want, double *out) {
   __shared__ double part[4];
   double acc = 0.0;
-  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n;
-       i += (uint64_t)gridDim.x * 256) {
+  // four independent (non-temporal) loads in flight per thread: a read-only pass is bound by the bytes in flight
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < n; i += 4 * stride) {
+    typename AmpT<R>::type a[4];
+    bool on[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      on[k] = ((i + k * stride) & mask) == want;
+      if (on[k]) a[k] = ld_amp<true>(psi + i + k * stride);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (on[k]) acc += (double)a[k].x * (double)a[k].x + (double)a[k].y * (double)a[k].y;
+  }
+  for (; i < n; i += stride) {
     if ((i & mask) == want) {
-      const auto a = psi[i];
+      const auto a = ld_amp<true>(psi + i);
       acc += (double)a.x * (double)a.x + (double)a.y * (double)a.y;
     }
   }
@@ -273,9 +287,23 @@ __global__ __launch_bounds__(256) void k_argmax(const typename AmpT<R>::type *__
   __shared__ uint64_t si[256];
   double bp = -1.0;
   uint64_t bi = 0;
-  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n;
-       i += (uint64_t)gridDim.x * 256) {
-    const auto a = psi[i];
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < n; i += 4 * stride) {      // four loads in flight per thread (indices ascending: first maximum wins)
+    typename AmpT<R>::type a[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a[k] = ld_amp<true>(psi + i + k * stride);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const double p = (double)a[k].x * (double)a[k].x + (double)a[k].y * (double)a[k].y;
+      if (p > bp) {
+        bp = p;
+        bi = i + k * stride;
+      }
+    }
+  }
+  for (; i < n; i += stride) {
+    const auto a = ld_amp<true>(psi + i);
     const double p = (double)a.x * (double)a.x + (double)a.y * (double)a.y;
     if (p > bp) {
       bp = p;

@@ -566,6 +566,7 @@ class Planner {
   bool defer_diag_ = env_flag("QH_DEFER_DIAG", true);   // see build_sweep
   bool lookahead_ = env_flag("QH_RELAYOUT_AHEAD", true); // see finish_relayout
   bool relayout_contig_ = env_flag("QH_RELAYOUT_CONTIG", false);   // see want_relayout
+  bool lswap_early_ = env_flag("QH_LSWAP_EARLY", true);            // lane <-> register exchange before the phases of its gate (emit_ops_with)
   std::vector<uint64_t> alg_override_;
   std::vector<uint32_t> weight_;  // reference gate applications each pending record stands for
   std::vector<std::vector<int>> tiles_ = parse_tiles(getenv("QH_FORCE_TILES"));   // "3,6,7;12,13" = tile bits of sweep 0; sweep 1 (experiments)
@@ -1304,6 +1305,17 @@ class Planner {
           wswap(wi, vr);
           swaps.push_back(Swap{1, wi, vr});
         }
+        // ... and so does a butterfly's target on lane bit 4 / 5 that is about to be exchanged with a register bit
+        // anyway: the phases waiting for it then multiply the 2^(RB-1) slots of that register bit with every lane
+        // at work (and can join a factor tree) instead of all 2^RB slots with half the lanes idle
+        const int bv = role[gi] == 1 ? butterfly_variant(r->g) : -1;
+        if (lswap_early_ && bv >= 0 && ch.lswap > 0 && lane_index(geom, r->tgt) >= 4) {
+          const int l0 = lane_index(geom, r->tgt);
+          ch.lswap--;
+          const int vr = victim_reg();
+          lswap(l0, vr);
+          swaps.push_back(Swap{0, l0, vr});
+        }
         const size_t n_ops_before = sp->ops.size();
         flush_diag(&pending, 1ull << r->tgt, sp, geom);
         // non-zero only when THIS flush emitted a DIAG op right in front of the dense op
@@ -1323,7 +1335,6 @@ class Planner {
         memcpy(op.g, r->g, sizeof op.g);
         if (role[gi] == 2) for (int k = 0; k < 4; ++k) cmul_acc(&op.g[2 * k], &op.g[2 * k + 1], sink_re[gi], sink_im[gi]);
         int li = lane_index(geom, r->tgt);
-        const int bv = role[gi] == 1 ? butterfly_variant(r->g) : -1;
         if (bv >= 0 && li >= 4 && ch.lswap > 0) {   // lane bit 4/5 <-> a register bit, then a register butterfly
           ch.lswap--;
           const int vr = victim_reg();

@@ -185,8 +185,8 @@ def test_non_eager_circuit_runs_as_planned_sweeps():
   qc.qft(reg)
   assert qc.ir.ngates == n * (n + 1) // 2 and qc._dev is None       # nothing executed yet
   qc.run()
+  qc.flush()                                     # (gates queue on the host side until something reads the state)
   dev = qc._dev
-  dev.flush()
   st = dev.stats()
   assert st['gates_submitted'] == n * (n + 1) // 2 and st['kernels_launched'] <= 4 and st['sweeps'] == st['kernels_launched']
   ks = (0, 1, 12345, (1 << n) - 1)

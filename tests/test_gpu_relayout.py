@@ -148,3 +148,41 @@ def test_device_pointer_is_canonical():
       st2.upload(ref)
       st2.run_stream(ops, g8)
       assert np.max(np.abs(st2.download() - st.download())) < 1e-12
+
+
+def test_device_ptr_stays_valid_across_later_gates(oracle):
+  """qh_device_ptr hands the raw pointer out (torch / dlpack interop fetches it once): queued gates run first, the
+  layout is canonical, and LATER gates must neither move the state to the other buffer nor permute it (ADVICE r2:
+  a relayout sweep after the call used to leave the caller with the stale scratch buffer)."""
+  n = 22
+  ops, g8 = _high_bit_circuit(n, 11)
+  more_ops, more_g = _high_bit_circuit(n, 12)
+  rng = np.random.default_rng(2)
+  psi0 = rng.standard_normal(1 << n) + 1j * rng.standard_normal(1 << n)
+  psi0 /= np.linalg.norm(psi0)
+  want1 = psi0.copy()
+  oracle.run_stream(want1, n, ops, g8)
+  want2 = want1.copy()
+  oracle.run_stream(want2, n, more_ops, more_g)
+  with device.DeviceState(n, 128, fusion=native.QH_FUSE_SWEEP) as st:
+    st.upload(psi0)
+    st.run_stream(ops[:30], g8[:30])
+    st.flush()                                   # relayout sweeps have run: the layout is permuted now
+    assert _bitmap(st, n) != list(range(n))
+    st.run_stream(ops[30:], g8[30:])             # ... and these are still queued when the pointer is asked for
+    ptr = st.device_ptr
+    assert _bitmap(st, n) == list(range(n))
+    raw = (ctypes.c_double * (2 << n))()
+    hip = ctypes.CDLL('libamdhip64.so.7')          # (the runtime the engine is linked against: already mapped)
+
+    def read():
+      st.sync()
+      assert hip.hipMemcpy(raw, ctypes.c_void_p(ptr), ctypes.c_size_t(16 << n), 2) == 0   # DeviceToHost through the RAW pointer
+      return np.frombuffer(raw, dtype=np.complex128).copy()
+
+    assert np.max(np.abs(read() - want1)) < 1e-12
+    st.run_stream(more_ops, more_g)              # scattered tiles again: would re-lay out if the handle still could
+    st.flush()
+    assert st.device_ptr == ptr and _bitmap(st, n) == list(range(n))
+    assert np.max(np.abs(read() - want2)) < 1e-12
+    assert np.max(np.abs(st.download() - want2)) < 1e-12

@@ -1,0 +1,18 @@
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r03f; mkdir -p $O
+timeout 600 python -m pytest tests/test_gpu_relayout.py tests/test_gpu_lib.py tests/test_gpu_parity.py -m gpu -q -x 2>&1 | tail -6 > $O/pytest.log; cat $O/pytest.log
+python tools/probes/readers_time.py 30 > $O/readers.txt 2>&1; cat $O/readers.txt
+for round in 1 2 3; do for v in 0 1; do for w in qft30 qft30c64 sup30 qft33; do
+  echo "## lswap_early$v $w round $round" >> $O/lswap_early.txt
+  QH_LSWAP_EARLY=$v QH_SWEEP_TIMING=1 timeout 200 python tools/run_workload.py $w 4 2>&1 | grep -a "qh sweeps" | tail -3 >> $O/lswap_early.txt
+done; done; done
+python3 - <<'PY'
+import re, collections, statistics
+cur=None; data=collections.defaultdict(list); per=collections.defaultdict(list)
+for l in open('gpurun_out/r03f/lswap_early.txt'):
+    if l.startswith('##'): cur=tuple(l.split()[1:3])
+    else:
+        v=[float(x) for x in re.findall(r'[0-9.]+',l.split(']')[1])]
+        data[cur].append(sum(v)); per[cur].append(v)
+for k in sorted(data, key=lambda k:(k[1],k[0])): print(k, 'median total ms %.3f  min %.3f  n %d'%(statistics.median(data[k]),min(data[k]),len(data[k])), 'per sweep', [round(statistics.median(x),3) for x in zip(*[p for p in per[k] if len(p)==len(per[k][0])])])
+PY
