@@ -566,6 +566,7 @@ class Planner {
   bool defer_diag_ = env_flag("QH_DEFER_DIAG", true);   // see build_sweep
   bool lookahead_ = env_flag("QH_RELAYOUT_AHEAD", true); // see finish_relayout
   bool relayout_contig_ = env_flag("QH_RELAYOUT_CONTIG", false);   // see want_relayout
+  bool reorder_ = env_flag("QH_REORDER", true);                    // see reorder_for_fewer_swaps
   bool lswap_early_ = env_flag("QH_LSWAP_EARLY", true);            // lane <-> register exchange before the phases of its gate (emit_ops_with)
   std::vector<uint64_t> alg_override_;
   std::vector<uint32_t> weight_;  // reference gate applications each pending record stands for
@@ -1147,7 +1148,71 @@ class Planner {
   // Diagonal gates are placed LAZILY: a phase term stays pending until a dense
   // op targets one of its bits (or the sweep ends), so the terms of many
   // reference gates meet in few DIAG ops and merge into tables.
-  void emit_ops(const std::vector<const GateRec *> &taken, SweepPlan *sp) {
+  // The gates of a sweep in an order that exchanges layouts less often.  Only five (six) of a tile's ten or more
+  // bits sit in registers at a time; a butterfly on lane bit 4 / 5 or on a wave bit first trades places with a register
+  // bit (LSWAP 72 VALU instructions, WSWAP 64 LDS accesses + a barrier).  A layered circuit visits its qubits round
+  // robin, so in queue order almost every dense gate of a supremacy sweep outside the registers costs an exchange
+  // (12 per sweep of ~37 dense gates).  Gates that commute may run in any order: list scheduling over the dependency
+  // graph (two gates depend on each other when one acts densely on a bit the other touches) -- take, in queue order,
+  // every ready gate whose target is in a register or on lane bits 0..3 (or that is diagonal); only when none is left
+  // take the first ready gate that needs an exchange, with the Belady victim.  Ghosts and their bits take part like any
+  // gate (rank-invariant).  The emission below then decides the real exchanges on the new order.
+  std::vector<const GateRec *> reorder_for_fewer_swaps(const std::vector<const GateRec *> &taken, const SweepPlan &sp) const {
+    const size_t n = taken.size();
+    if (!reorder_ || n < 4 || n > 600 || (sp.nwave == 0 && sp.nlanehi() < 2)) return taken;
+    std::vector<uint64_t> dense(n), all(n);
+    for (size_t i = 0; i < n; ++i) {
+      const GateRec &r = *taken[i];
+      const uint64_t tb = r.tgt >= 0 ? (1ull << r.tgt) : 0;
+      dense[i] = plan_diag(r) ? 0 : tb;
+      all[i] = tb | r.ctl_mask | r.neg_mask;
+    }
+    std::vector<int> ndep(n, 0);
+    std::vector<std::vector<uint32_t>> succ(n);
+    for (size_t j = 0; j < n; ++j)
+      for (size_t i = 0; i < j; ++i)
+        if ((dense[i] & all[j]) || (dense[j] & all[i])) { succ[i].push_back((uint32_t)j); ndep[j]++; }
+    uint64_t regs = 0, cheap = (1ull << sp.lane_low) - 1;        // where a dense gate needs no exchange
+    for (int k = 0; k < sp.rb; ++k) regs |= 1ull << sp.regpos[k];
+    for (int k = 0; k < sp.nlanehi(); ++k) if (sp.lane_low + k < 4) cheap |= 1ull << sp.lanehi[k];   // lane bit 3: DPP, no exchange
+    std::vector<uint8_t> done(n, 0);
+    std::vector<const GateRec *> out;
+    out.reserve(n);
+    size_t scheduled = 0;
+    auto take = [&](size_t i) {
+      done[i] = 1;
+      out.push_back(taken[i]);
+      ++scheduled;
+      for (uint32_t j : succ[i]) ndep[j]--;
+    };
+    while (scheduled < n) {
+      bool progress = true;
+      while (progress) {                       // everything that runs where the bits are now, in queue order
+        progress = false;
+        for (size_t i = 0; i < n; ++i)
+          if (!done[i] && ndep[i] == 0 && (!dense[i] || (dense[i] & (regs | cheap)))) { take(i); progress = true; }
+      }
+      if (scheduled == n) break;
+      size_t pick = n;
+      for (size_t i = 0; i < n; ++i) if (!done[i] && ndep[i] == 0) { pick = i; break; }
+      if (pick == n) return taken;             // (cannot happen: the dependency graph follows the queue order)
+      // the register bit that gives way: the one used as a dense target LATEST among the gates still to come
+      int victim = -1;
+      size_t victim_next = 0;
+      for (uint64_t t = regs; t; t &= t - 1) {
+        const int b = __builtin_ctzll(t);
+        size_t next = n + 1;
+        for (size_t j = 0; j < n; ++j) if (!done[j] && j != pick && (dense[j] >> b & 1ull)) { next = j; break; }
+        if (victim < 0 || next > victim_next) { victim = b; victim_next = next; }
+      }
+      if (victim >= 0) regs = (regs & ~(1ull << victim)) | dense[pick];
+      take(pick);
+    }
+    return out;
+  }
+
+  void emit_ops(const std::vector<const GateRec *> &taken_in, SweepPlan *sp) {
+    const std::vector<const GateRec *> taken = reorder_for_fewer_swaps(taken_in, *sp);
     emit_ops_with(taken, sp, LaneChoice{});
     if (lane_valu_) {
       LaneChoice ch = choose_lane_paths(*sp);     // (ghost ops count: the choice must not depend on the rank)
