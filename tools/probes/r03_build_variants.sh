@@ -11,19 +11,13 @@ build() {  # build <tag> <load bits> <store bits>
   cp $R/qcc_amd/csrc/*.h $R/qcc_amd/csrc/*.hip $R/qcc_amd/csrc/*.cc $R/qcc_amd/csrc/sweep_handlers.inc $d/qcc_amd/csrc/
   cp $R/include/*.h $d/include/
   QH_ISLAND_LD_BITS="$ld" QH_ISLAND_ST_BITS="$st" QH_ISLAND_OUT=$d/qcc_amd/csrc python3 $R/tools/gen_sweep_asm.py > /dev/null
-  (cd $d && hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -o $V/libqcc_$tag.so qcc_amd/csrc/engine.hip qcc_amd/csrc/libq_facade.cc 2>&1 | grep -v "warning: ignoring\|^$" | head -5)
+  (cd $d && hipcc --offload-arch=gfx950 -O3 -std=c++17 $EXTRA_FLAGS -shared -fPIC -o $V/libqcc_$tag.so qcc_amd/csrc/engine.hip qcc_amd/csrc/libq_facade.cc 2>&1 | grep -v "warning: ignoring\|^$" | head -5)
   echo "built $tag: loads '$ld' stores '$st'"
 }
-# round-3 batch 1 (nt/plain/sc0/sc1 one side at a time): stores "sc1 nt" -2.3 % on the QFT, everything else within 1 %
+# round-3 batch 3 (QH_ISLAND_BATCH 4 / 8 / 16 slot offsets per scalar round trip): no difference beyond the noise
+# round-3 batch 4: what the lane-table copy to LDS at the start of every workgroup costs (-DQH_SKIP_LTAB_COPY: timing only)
 build nt_nt "nt" "nt" &
-build nt_sc1nt "nt" "sc1 nt" &
-build sc1nt_sc1nt "sc1 nt" "sc1 nt" &
-wait
-build sc01nt_sc1nt "sc0 sc1 nt" "sc1 nt" &
-build nt_sc1 "nt" "sc1" &
-build sc0nt_sc1nt "sc0 nt" "sc1 nt" &
-wait
-build plain_sc1nt "" "sc1 nt" &
-build sc1nt_sc01nt "sc1 nt" "sc0 sc1 nt" &
+EXTRA_FLAGS=-DQH_SKIP_LTAB_COPY build skipcopy "nt" "nt" &
+EXTRA_FLAGS=-DQH_ZERO_LTAB build onesltab "nt" "nt" &
 wait
 ls -la $V

@@ -4,10 +4,10 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r03v
 mkdir -p $O
-for round in 1 2 3 4 5; do
+for round in 1 2 3 4 5 6 7 8; do
   for lib in $R/tools/probes/variants/libqcc_*.so; do
     tag=$(basename $lib .so)
-    for w in qft30 qft30c64 qft33; do
+    for w in qft30 qft30c64; do
       echo "## $tag $w round $round $EXTRA" >> $O/variants.txt
       QCC_HIP_LIB=$lib QH_SWEEP_TIMING=1 timeout 200 python $R/tools/run_workload.py $w 4 2>&1 | grep -a "qh sweeps" | tail -3 >> $O/variants.txt
     done
