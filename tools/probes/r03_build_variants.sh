@@ -15,9 +15,10 @@ build() {  # build <tag> <load bits> <store bits>
   echo "built $tag: loads '$ld' stores '$st'"
 }
 # round-3 batch 3 (QH_ISLAND_BATCH 4 / 8 / 16 slot offsets per scalar round trip): no difference beyond the noise
-# round-3 batch 4: what the lane-table copy to LDS at the start of every workgroup costs (-DQH_SKIP_LTAB_COPY: timing only)
+# round-3 batch 4 (-DQH_SKIP_LTAB_COPY / -DQH_ZERO_LTAB: what the lane-table copy in front of the loads costs): complex64 -6 %
+# round-3 batch 5: a window on the tile loads in flight per wave (QH_ISLAND_LOAD_WINDOW)
 build nt_nt "nt" "nt" &
-EXTRA_FLAGS=-DQH_SKIP_LTAB_COPY build skipcopy "nt" "nt" &
-EXTRA_FLAGS=-DQH_ZERO_LTAB build onesltab "nt" "nt" &
+QH_ISLAND_LOAD_WINDOW=8 build win8 "nt" "nt" &
+QH_ISLAND_LOAD_WINDOW=16 build win16 "nt" "nt" &
 wait
 ls -la $V

@@ -4,7 +4,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r03v
 mkdir -p $O
-for round in 1 2 3 4 5 6 7 8; do
+for round in 1 2 3 4 5 6; do
   for lib in $R/tools/probes/variants/libqcc_*.so; do
     tag=$(basename $lib .so)
     for w in qft30 qft30c64; do
