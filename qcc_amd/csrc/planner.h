@@ -566,6 +566,7 @@ class Planner {
   bool defer_diag_ = env_flag("QH_DEFER_DIAG", true);   // see build_sweep
   bool lookahead_ = env_flag("QH_RELAYOUT_AHEAD", true); // see finish_relayout
   bool relayout_contig_ = env_flag("QH_RELAYOUT_CONTIG", false);   // see want_relayout
+  bool lane3_least_ = env_flag("QH_LANE3_LEAST", false);           // see build_sweep (measured slower: off)
   bool reorder_ = env_flag("QH_REORDER", true);                    // see reorder_for_fewer_swaps
   bool lswap_early_ = env_flag("QH_LSWAP_EARLY", true);            // lane <-> register exchange before the phases of its gate (emit_ops_with)
   std::vector<uint64_t> alg_override_;
@@ -1015,6 +1016,21 @@ class Planner {
         regmask = mask_of(regs);
         lanemask = always | mask_of(lanehi);
       }
+    }
+    // Of the three movable lane bits of a complex128 tile, lane bit 3 is the expensive seat: its butterflies fetch the
+    // partner by DPP (192 VALU instructions each, and their phases multiply all 32 slots), while lane bits 4 / 5 trade
+    // places with a register bit once (72) and run their gates there.  In a split-lane tile any index bit may take any
+    // lane role: the bit with the fewest dense gates takes lane bit 3.  MEASURED SLOWER (supremacy-30 32.9 -> 34.1 ms:
+    // saves four DPP butterflies per circuit but, where index bit 3 was a lane bit, breaks the 256-byte runs of lanes
+    // 0..15 into 128-byte ones), so it is off; kept for the record (QH_LANE3_LEAST=1).
+    if (lane3_least_ && lane_low_ == 3 && lanehi.size() == 3 &&
+        !(lanehi[0] == 3 && lanehi[1] == 4 && lanehi[2] == 5)) {
+      std::vector<int> cnt(64, 0);
+      for (const GateRec *r : taken)
+        if (!plan_diag(*r) && r->tgt >= 0) cnt[r->tgt]++;
+      size_t best = 0;
+      for (size_t i = 1; i < lanehi.size(); ++i) if (cnt[lanehi[i]] < cnt[lanehi[best]]) best = i;
+      if (best != 0) std::rotate(lanehi.begin(), lanehi.begin() + (long)best, lanehi.begin() + (long)best + 1);
     }
     // drop register bits that ended up unused (a later candidate made them moot)
     {
