@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstddef>
@@ -286,6 +287,28 @@ bool relayout_wanted(const qh_state_s *h) {
   if (h->relayout >= 0) return h->relayout == 1;
   return relayout_eligible(h) && !(h->comm && h->comm->nranks > 1);
 }
+// A state buffer.  QH_ALLOC_CONTIG=1 asks the driver for PHYSICALLY contiguous VRAM first (hipDeviceMallocContiguous):
+// the page tables then describe the buffer with the largest fragments the translation caches know, which is what the
+// gather sweeps (lines up to 16 MiB apart) live on; if the driver has no contiguous range left it is plain hipMalloc.
+hipError_t alloc_state_buffer(void **p, size_t bytes) {
+  static const int contig = env_int("QH_ALLOC_CONTIG", 0), debug = env_int("QH_ALLOC_DEBUG", 0);
+  const auto t0 = std::chrono::steady_clock::now();
+  hipError_t e = hipErrorOutOfMemory;
+  bool got_contig = false;
+  if (contig && bytes >= (64ull << 20)) {
+    e = hipExtMallocWithFlags(p, bytes, hipDeviceMallocContiguous);
+    got_contig = e == hipSuccess;
+    if (!got_contig) {
+      (void)hipGetLastError();
+      *p = nullptr;
+    }
+  }
+  if (!got_contig) e = hipMalloc(p, bytes);
+  if (debug)
+    fprintf(stderr, "[qh alloc %zu MiB %s at %p in %.1f ms]\n", bytes >> 20, got_contig ? "contiguous" : "plain", *p,
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+  return e;
+}
 bool alloc_second_buffer(qh_state_s *h) {
   if (h->d_alt) return true;
   const size_t bytes = (size_t)h->amp_bytes() << h->nloc;
@@ -293,7 +316,7 @@ bool alloc_second_buffer(qh_state_s *h) {
   // (a communicator of several ranks will want its staging halves too: up to 4 x (P-1) x chunk amplitudes)
   const size_t reserve = (bytes >> 5) + (3ull << 29) + ((h->comm && h->comm->nranks > 1) ? (4ull << 30) : 0);
   if (hipMemGetInfo(&fr, &total) == hipSuccess && fr > bytes + reserve &&
-      hipMalloc(&h->d_alt, bytes) == hipSuccess)
+      alloc_state_buffer(&h->d_alt, bytes) == hipSuccess)
     return true;
   (void)hipGetLastError();
   h->d_alt = nullptr;
@@ -534,7 +557,7 @@ int qh_create(int nbits, int bit_width, int device, qh_handle *out) {
   h->bw = bit_width;
   h->device = device;
   const uint64_t bytes = (1ull << nbits) * h->amp_bytes();
-  hipError_t e = hipMalloc(&h->d_psi, bytes);
+  hipError_t e = alloc_state_buffer(&h->d_psi, bytes);
   if (e != hipSuccess) {
     delete h;
     return fail(QH_ERR_NOMEM, "hipMalloc(%llu bytes) for %d qubits: %s", (unsigned long long)bytes,
