@@ -222,6 +222,13 @@ class qc:
         if self._nbits == 0:
             raise ValueError('circuit has no qubits yet')
         if self._dev is not None and (self._dev.nbits != self._nbits or self._dev.bit_width != self._width()):
+            if (self._dev_ok and not self._host_ok and not self._product_flag and self._dev.nbits == self._nbits):
+                # the tensor width changed under a live state (the reference silently stops applying gates then,
+                # SURVEY appendix B Q1): carry the amplitudes over through the host
+                if self._nbits > _SNAPSHOT_LIMIT_BITS:
+                    raise ValueError(f'tensor width changed to {self._width()} while a {self._nbits}-qubit state is '
+                                     f'resident at width {self._dev.bit_width}')
+                self._host, self._host_ok = state.State(self._dev.download()), True
             if not self._alias:
                 self._dev.close()     # (alias mode: State views handed out keep the mapped memory alive)
             self._dev, self._dev_ok = None, False

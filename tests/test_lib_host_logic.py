@@ -220,6 +220,25 @@ def test_complex64_policy():
   assert np.allclose(np.abs(qc.psi) ** 2, [0, 0.5, 0, 0, 0.5, 0, 0, 0], atol=1e-6)
 
 
+def test_width_change_under_a_live_state_keeps_the_amplitudes():
+  """The reference silently stops applying gates when tensor_width no longer matches psi's dtype (SURVEY appendix B,
+  Q1); here the state is carried over to the new width, with gates still queued on the host side."""
+  tensor.set_tensor_width(128)
+  try:
+    qc = circuit.qc('w')
+    qc.reg(3, 1)
+    qc.h(0); qc.cx(0, 2); qc.flush()
+    qc.h(1)                                  # queued on the host side at width 128
+    tensor.set_tensor_width(64)
+    qc.x(2)
+    psi = np.asarray(qc.psi)
+    assert psi.dtype == np.complex64 and qc._dev.bit_width == 64
+    want = np.zeros(8); want[[0, 2, 5, 7]] = 0.25
+    assert np.allclose(np.abs(psi) ** 2, want, atol=1e-6)
+  finally:
+    tensor.set_tensor_width(128)
+
+
 def alias_contract(make_qc, oracle_apply):
   """The reference's in-place contract (src/lib/xgates.cc:37-38; relied on by code that keeps `psi`
   around): shared by the CPU stand-in test below and tests/test_gpu_lib.py on the real host-mapped state."""
