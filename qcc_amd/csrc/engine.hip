@@ -287,15 +287,18 @@ bool relayout_wanted(const qh_state_s *h) {
   if (h->relayout >= 0) return h->relayout == 1;
   return relayout_eligible(h) && !(h->comm && h->comm->nranks > 1);
 }
-// A state buffer.  QH_ALLOC_CONTIG=1 asks the driver for PHYSICALLY contiguous VRAM first (hipDeviceMallocContiguous):
-// the page tables then describe the buffer with the largest fragments the translation caches know, which is what the
-// gather sweeps (lines up to 16 MiB apart) live on; if the driver has no contiguous range left it is plain hipMalloc.
+// A state buffer.  Buffers of 4..32 GiB (QH_ALLOC_CONTIG=1: every buffer >= 64 MiB, =0: none) are asked for as
+// PHYSICALLY contiguous VRAM first (hipDeviceMallocContiguous); if the driver has no contiguous range left it is plain
+// hipMalloc.  Measured, not derived (DESIGN 7 "placement", profiles/r03/alloc_contiguous_*): where the driver puts a
+// buffer decides +-2.5 % of a sweep's time; contiguous 8- and 16-GiB buffers land in the fast mode 11 times of 12
+// (30-qubit QFT 16.54 ms mean vs 16.92 over 12 interleaved fresh processes), a contiguous 256-GiB state is 6 % slower.
 hipError_t alloc_state_buffer(void **p, size_t bytes) {
-  static const int contig = env_int("QH_ALLOC_CONTIG", 0), debug = env_int("QH_ALLOC_DEBUG", 0);
+  static const int contig = env_int("QH_ALLOC_CONTIG", -1), debug = env_int("QH_ALLOC_DEBUG", 0);
   const auto t0 = std::chrono::steady_clock::now();
   hipError_t e = hipErrorOutOfMemory;
   bool got_contig = false;
-  if (contig && bytes >= (64ull << 20)) {
+  const bool want_contig = contig < 0 ? (bytes >= (4ull << 30) && bytes <= (32ull << 30)) : (contig > 0 && bytes >= (64ull << 20));
+  if (want_contig) {
     e = hipExtMallocWithFlags(p, bytes, hipDeviceMallocContiguous);
     got_contig = e == hipSuccess;
     if (!got_contig) {
