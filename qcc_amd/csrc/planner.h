@@ -408,14 +408,15 @@ class Planner {
     const int cap = lane_hi_ + rb_cap_ + max_wave_;
     if ((size_t)popc(movable) > K * (size_t)cap) return false;       // not even room to visit every qubit once
     uint64_t rng = 0x9e3779b97f4a7c15ull;
+    if (const char *e = getenv("QH_PLAN_SEARCH_SEED")) rng ^= strtoull(e, nullptr, 10) * 0xd1342543de82ef95ull;   // (experiments)
     auto rnd = [&](uint32_t n) { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return (uint32_t)((rng >> 11) % n); };
     auto pick_bit = [&](uint64_t m) { int k = (int)rnd((uint32_t)popc(m)); while (k--) m &= m - 1; return __builtin_ctzll(m); };
-    std::vector<uint64_t> cur, best_tiles;
+    std::vector<uint64_t> start, cur, best_tiles;
     for (size_t k = 0; k < K; ++k) {
       uint64_t t = 0;
       for (uint64_t m = greedy_tiles[k] & ~always; m; m &= m - 1)
         if (canon[__builtin_ctzll(m)] >= 0) t |= 1ull << canon[__builtin_ctzll(m)];
-      cur.push_back(t & movable);
+      start.push_back(t & movable);
     }
     std::vector<SearchSweep> st(K), trial(K);
     uint64_t steps = 0;
@@ -423,50 +424,67 @@ class Planner {
       for (size_t i = from; i < K; ++i) search_run(i ? (*out)[i - 1].rest : rec0, always | tiles[i], &(*out)[i], &steps);
       return (*out)[K - 1].rest.size();
     };
-    size_t cv = eval_from(cur, 0, &st), best = cv;
-    best_tiles = cur;
-    size_t since_improved = 0, walks_without_gain = 0;
-    while (best > 0 && steps < step_budget && walks_without_gain < 4) {
-      const size_t i = rnd((uint32_t)K);
-      const uint64_t s = cur[i];
-      uint64_t wantb = st[i].want & ~s & movable;
-      if (!wantb || rnd(100) < 15) wantb = movable & ~s;
-      if (!wantb) continue;
-      uint64_t ns = s | (1ull << pick_bit(wantb));
-      if (popc(s) >= cap || rnd(100) >= 70) {
-        if (!s) continue;
-        uint32_t m = ~0u;
-        for (uint64_t t = s; t; t &= t - 1) m = std::min(m, st[i].cnt[__builtin_ctzll(t)]);
-        const uint32_t slack = rnd(100) < 30 ? 1 : 0;
-        uint64_t pool = 0;
-        for (uint64_t t = s; t; t &= t - 1) if (st[i].cnt[__builtin_ctzll(t)] <= m + slack) pool |= t & -t;
-        ns &= ~(1ull << pick_bit(pool));
-      }
-      if (ns == s || popc(ns) > cap) continue;       // (whether the positions suit a tile is checked when the plan is built)
-      for (size_t k = 0; k < i; ++k) trial[k].rest.clear();          // (prefix unchanged: evaluated from sweep i on)
-      std::vector<uint64_t> cand = cur;
-      cand[i] = ns;
-      // sweeps before i are those of `st`: run i.. on top of st[i-1]
-      {
-        const std::vector<PassRec> *src = i ? &st[i - 1].rest : &rec0;
-        search_run(*src, always | cand[i], &trial[i], &steps);
-        for (size_t k = i + 1; k < K; ++k) search_run(trial[k - 1].rest, always | cand[k], &trial[k], &steps);
-      }
-      const size_t v = trial[K - 1].rest.size();
-      if (v <= cv) {
-        for (size_t k = i; k < K; ++k) std::swap(st[k], trial[k]);
-        cur.swap(cand);
-        if (v < cv) since_improved = 0;
-        cv = v;
-        if (v < best) { best = v; best_tiles = cur; walks_without_gain = 0; }
-      }
-      if (++since_improved > 1500) {        // stuck on a plateau: back to the best tiles, another walk
-        cur = best_tiles;
-        cv = eval_from(cur, 0, &st);
-        since_improved = 0;
-        ++walks_without_gain;               // (four walks from the best tiles without a better one: give up)
+    // The time a walk needs is heavy-tailed (supremacy-30, eight generators: 0.07-0.55 M gate visits when it
+    // succeeds, 3-5 M burnt when it has walked into a basin without a solution), so the budget is spent on
+    // ATTEMPTS: each starts from the greedy tiles with its own generator and gets an eighth of the budget (at least
+    // 0.3 M visits); the first that empties the queue wins.
+    static const int attempts = std::max(1, env_int("QH_PLAN_SEARCH_ATTEMPTS", 8));
+    const uint64_t attempt_budget = std::max<uint64_t>(step_budget / attempts, 300000);
+    size_t best = ~(size_t)0;
+    const uint64_t rng0 = rng;
+    for (uint64_t attempt = 0; best > 0 && steps < step_budget; ++attempt) {
+      rng = rng0 + attempt * 0xd1342543de82ef95ull;
+      if (!rng) rng = rng0;
+      const uint64_t attempt_end = std::min(step_budget, steps + attempt_budget);
+      cur = start;
+      size_t cv = eval_from(cur, 0, &st), abest = cv;
+      std::vector<uint64_t> abest_tiles = cur;
+      if (cv < best) { best = cv; best_tiles = cur; }
+      size_t since_improved = 0, walks_without_gain = 0;
+      while (best > 0 && steps < attempt_end && walks_without_gain < 4) {
+        const size_t i = rnd((uint32_t)K);
+        const uint64_t s = cur[i];
+        uint64_t wantb = st[i].want & ~s & movable;
+        if (!wantb || rnd(100) < 15) wantb = movable & ~s;
+        if (!wantb) continue;
+        uint64_t ns = s | (1ull << pick_bit(wantb));
+        if (popc(s) >= cap || rnd(100) >= 70) {
+          if (!s) continue;
+          uint32_t m = ~0u;
+          for (uint64_t t = s; t; t &= t - 1) m = std::min(m, st[i].cnt[__builtin_ctzll(t)]);
+          const uint32_t slack = rnd(100) < 30 ? 1 : 0;
+          uint64_t pool = 0;
+          for (uint64_t t = s; t; t &= t - 1) if (st[i].cnt[__builtin_ctzll(t)] <= m + slack) pool |= t & -t;
+          ns &= ~(1ull << pick_bit(pool));
+        }
+        if (ns == s || popc(ns) > cap) continue;       // (whether the positions suit a tile is checked when the plan is built)
+        for (size_t k = 0; k < i; ++k) trial[k].rest.clear();          // (prefix unchanged: evaluated from sweep i on)
+        std::vector<uint64_t> cand = cur;
+        cand[i] = ns;
+        // sweeps before i are those of `st`: run i.. on top of st[i-1]
+        {
+          const std::vector<PassRec> *src = i ? &st[i - 1].rest : &rec0;
+          search_run(*src, always | cand[i], &trial[i], &steps);
+          for (size_t k = i + 1; k < K; ++k) search_run(trial[k - 1].rest, always | cand[k], &trial[k], &steps);
+        }
+        const size_t v = trial[K - 1].rest.size();
+        if (v <= cv) {
+          for (size_t k = i; k < K; ++k) std::swap(st[k], trial[k]);
+          cur.swap(cand);
+          if (v < cv) since_improved = 0;
+          cv = v;
+          if (v < abest) { abest = v; abest_tiles = cur; walks_without_gain = 0; }
+          if (v < best) { best = v; best_tiles = cur; }
+        }
+        if (++since_improved > 1500) {        // stuck on a plateau: back to this attempt's best tiles, another walk
+          cur = abest_tiles;
+          cv = eval_from(cur, 0, &st);
+          since_improved = 0;
+          ++walks_without_gain;               // (four walks from the best tiles without a better one: next attempt)
+        }
       }
     }
+    if (getenv("QH_PLAN_SEARCH_DEBUG")) fprintf(stderr, "[qh search K=%zu left=%zu visits=%llu]\n", K, best, (unsigned long long)steps);
     if (best > 0) return false;
     tiles_out->clear();
     for (uint64_t t : best_tiles) {
