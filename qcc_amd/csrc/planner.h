@@ -427,17 +427,21 @@ class Planner {
     // The time a walk needs is heavy-tailed (supremacy-30, eight generators: 0.07-0.55 M gate visits when it
     // succeeds, 3-5 M burnt when it has walked into a basin without a solution), so the budget is spent on
     // ATTEMPTS: each starts from the greedy tiles with its own generator and gets an eighth of the budget (at least
-    // 0.3 M visits); the first that empties the queue wins.
+    // 0.3 M visits); the first that empties the queue wins.  Circuits without a solution mostly show it at once (the
+    // 34-qubit Grover iteration, one supremacy instance in twelve: no move ever lowers the left-over): two attempts in
+    // a row without any progress end the search.
     static const int attempts = std::max(1, env_int("QH_PLAN_SEARCH_ATTEMPTS", 8));
     const uint64_t attempt_budget = std::max<uint64_t>(step_budget / attempts, 300000);
     size_t best = ~(size_t)0;
     const uint64_t rng0 = rng;
-    for (uint64_t attempt = 0; best > 0 && steps < step_budget; ++attempt) {
+    int fruitless = 0;       // attempts in a row that never got below the greedy tiles' left-over: two -> give up
+    for (uint64_t attempt = 0; best > 0 && steps < step_budget && fruitless < 2; ++attempt) {
       rng = rng0 + attempt * 0xd1342543de82ef95ull;
       if (!rng) rng = rng0;
       const uint64_t attempt_end = std::min(step_budget, steps + attempt_budget);
       cur = start;
       size_t cv = eval_from(cur, 0, &st), abest = cv;
+      const size_t start_left = cv;
       std::vector<uint64_t> abest_tiles = cur;
       if (cv < best) { best = cv; best_tiles = cur; }
       size_t since_improved = 0, walks_without_gain = 0;
@@ -483,6 +487,8 @@ class Planner {
           ++walks_without_gain;               // (four walks from the best tiles without a better one: next attempt)
         }
       }
+      fruitless = abest == start_left ? fruitless + 1 : 0;
+      if (getenv("QH_PLAN_SEARCH_DEBUG")) fprintf(stderr, "[qh search attempt %llu: left=%zu %s visits=%llu]\n", (unsigned long long)attempt, abest, walks_without_gain >= 4 ? "stuck" : (abest ? "budget" : "solved"), (unsigned long long)steps);
     }
     if (getenv("QH_PLAN_SEARCH_DEBUG")) fprintf(stderr, "[qh search K=%zu left=%zu visits=%llu]\n", K, best, (unsigned long long)steps);
     if (best > 0) return false;
