@@ -241,6 +241,12 @@ def test_tile_search_saves_a_sweep_and_keeps_the_amplitudes(oracle, monkeypatch)
   searched = _plan(30, ops, g8)
   assert greedy == 5 and len(searched['sweeps']) == 4
   assert sum(s['gates'] for s in searched['sweeps']) + searched['noop_gates'] == len(ops)
+  # the budget is spent on independent attempts (walks are heavy-tailed): seed 1 gets 6 -> 5, which one long walk misses
+  ops1, g81 = workloads.supremacy_stream(30, 20, seed=1).arrays()
+  monkeypatch.setenv('QH_PLAN_SEARCH_STEPS', '4000000')      # (pinned: the default scales with the sweep time)
+  assert len(_plan(30, ops1, g81)['sweeps']) == 5
+  again = _plan(30, ops, g8)                                 # deterministic: same circuit, same tiles
+  assert [s['regpos'] for s in again['sweeps']] == [s['regpos'] for s in _plan(30, ops, g8)['sweeps']]
   monkeypatch.setenv('QH_PLAN_SEARCH_STEPS', '4000000')      # (small states get no budget by default: a sweep is cheap there)
   rng = np.random.default_rng(16)
   for n, seed in ((16, 0), (17, 3), (15, 1)):
