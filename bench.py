@@ -341,19 +341,46 @@ def main():
   args.qubits_shard = nloc
   fusion = args.fusion if args.fusion >= 0 else native.QH_FUSE_SWEEP
 
+  def fail_line(stage, exc, eng=None):
+    """Multi-GPU runs: a transport that cannot be set up, ranks that disagree about an exchange, a peer that never
+    shows up (engine watchdog, QH_COMM_TIMEOUT_MS) end in ONE JSON line with "error" -- never in a silent switch to
+    another data path, never in a hang.  Every failing rank reports on stderr; rank 0 (or the failing rank, if rank 0
+    cannot know) prints the line; the process exits non-zero without waiting for peers that may be stuck."""
+    msg = f'{type(exc).__name__}: {exc}'
+    print(f'[bench.py rank {rank}/{world}] {stage} failed: {msg}', file=sys.stderr, flush=True)
+    line = {'metric': 'gate-applies/sec (2^30-amplitude units), QFT', 'value': None, 'unit': 'gate-applies/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': None, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': f'{n}-qubit QFT complex128 (failed before a result)', 'qubits': n},
+            'error': msg, 'error_stage': stage, 'error_rank': rank,
+            'exchange_path': getattr(eng, 'exchange_path', None)}
+    print(json.dumps(line), flush=True)
+    os._exit(3)
+
   dist = None
-  if world > 1 or args.sharded:
-    from qcc_amd import sharded
-    eng = sharded.ShardedState(n, fusion=fusion, local_rank=local_rank)
-    dist = eng.dist
-  else:
-    eng = device.DeviceState(n, 128, device=local_rank, fusion=fusion)
+  eng = None
+  try:
+    if world > 1 or args.sharded:
+      from qcc_amd import sharded
+      eng = sharded.ShardedState(n, fusion=fusion, local_rank=local_rank)
+      dist = eng.dist
+    else:
+      eng = device.DeviceState(n, 128, device=local_rank, fusion=fusion)
+  except Exception as e:  # pylint: disable=broad-except
+    if world == 1:
+      raise
+    fail_line('setup (process group / engine / exchange transport)', e, eng)
 
   ops, g8 = workloads.qft_stream(range(n)).arrays()
   ngates = len(ops)
   x = 0x12CB9A5E3 & ((1 << n) - 1)
-  eng.init_basis(x)
-  wall, ev_ms, stats = timed_steps(eng, ops, g8, args.steps, args.warmup, dist)
+  try:
+    eng.init_basis(x)
+    wall, ev_ms, stats = timed_steps(eng, ops, g8, args.steps, args.warmup, dist)
+  except Exception as e:  # pylint: disable=broad-except
+    if world == 1:
+      raise
+    fail_line('timed steps', e, eng)
 
   # parity guard inside the bench: closed form on sampled amplitudes after the
   # first full QFT is checked in tests; here we check the norm (cheap, device-side)
@@ -435,6 +462,8 @@ def main():
       out['xgmi_bytes_per_rank_per_step'] = stats.get('exchanged_bytes', 0) / steps
       out['exchange_ms_per_step_rank0'] = stats.get('exchange_seconds', 0.0) / steps * 1e3
       out['exchange_path'] = stats.get('exchange_path')
+      out['exchange_geometry'] = stats.get('exchange_geometry')     # slabs, rounds, chunk, packed / direct, staging bytes (rank 0)
+      out['relayout_on_every_rank'] = getattr(eng, 'relayout', None)
       if stats.get('exchange_seconds', 0.0) > 0:
         out['xgmi_GBps_per_rank'] = stats.get('exchanged_bytes', 0) / stats['exchange_seconds'] / 1e9
   if dist is not None:

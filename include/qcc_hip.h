@@ -186,6 +186,26 @@ typedef struct {
   uint64_t rounds_packed;    /* rounds moved through the gather / scatter kernels (blocks
                                 without long contiguous runs: after relayout sweeps)       */
 } qh_xstats;
+/* How the last qh_exchange_* call of a handle was cut.  Every field must be the same on every rank (the planner keeps
+ * rank-dependent gates as ghosts so that it is; `signature` is what the ranks compare before data moves): tools and tests
+ * read it, on real handles and -- without any device -- on planner-only ones (qh_create_dry + qh_comm_init_dry).        */
+typedef struct {
+  uint64_t signature;        /* 64-bit hash of everything below + the bit map + planner switches + build            */
+  uint64_t slab_mask;        /* local index bits whose values number the slabs (layout after the queued sweeps)     */
+  uint64_t block_bits;       /* local index bits that select the block a peer gets                                  */
+  uint64_t rounds_per_slab;  /* grouped send/recv rounds per slab                                                   */
+  uint64_t staging_bytes;    /* staging area this exchange needs (receive halves + send halves of packed rounds)    */
+  uint32_t slabs;            /* 2^popcount(slab_mask)                                                               */
+  uint32_t chunk_bits;       /* log2(amplitudes per peer and round)                                                 */
+  uint32_t packed;           /* 1: rounds go through the gather / scatter kernels, 0: sent from where they lie      */
+  uint32_t peers;            /* peers per round                                                                     */
+  uint32_t sweeps_before;    /* sweeps the queued gates were planned into (the last one precedes the exchange)      */
+  uint32_t last_sweep_split; /* 1: that last sweep was launched slab by slab (overlaps the exchange)                */
+} qh_xgeom;
+int qh_exchange_geometry(qh_handle h, qh_xgeom *out);
+/* Planner-only counterpart of qh_comm_init for handles made by qh_create_dry: qh_exchange_* then plan the queued gates,
+ * decide slabs, rounds, chunk size and path exactly as a real handle of that rank would, and move nothing.          */
+int qh_comm_init_dry(qh_handle h, int nranks, int rank);
 int qh_comm_unique_id(void *id /* QH_COMM_ID_BYTES, rank 0; broadcast by the caller */);
 int qh_comm_init(qh_handle h, int nranks, int rank, const void *id);
 int qh_comm_init_custom(qh_handle h, int nranks, int rank, qh_round_fn fn, void *user);
@@ -202,6 +222,11 @@ int qh_exchange_pair(qh_handle h, int shard_bit, int local_bit, uint64_t chunk_a
  * rounds / staging / slabs as a real exchange.                                              */
 int qh_exchange_loopback(qh_handle h, int local_bit, uint64_t chunk_amps);
 int qh_exchange_wait(qh_handle h);                 /* host wait for all arrivals             */
+/* Host waits of a handle whose communicator has several ranks are bounded: if the stream has not drained within
+ * QH_COMM_TIMEOUT_MS (default 300000) -- a peer is missing, or the ranks disagree about a round -- the call returns
+ * QH_ERR_COMM instead of hanging, and the handle refuses further work.  Before data moves the ranks compare a signature
+ * of the exchange geometry (every geometry a communicator has not seen yet; QH_EXCHANGE_VERIFY=1 every exchange, =0
+ * never): a disagreement is QH_ERR_COMM with both signatures in qh_last_error().                                    */
 int qh_exchange_stats(qh_handle h, qh_xstats *out);
 /* sum over ranks of `count` doubles, in place (RCCL transport only): norms, probabilities    */
 int qh_comm_allreduce_sum(qh_handle h, double *inout, int count);

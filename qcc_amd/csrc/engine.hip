@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <string>
 #include <vector>
 
@@ -134,9 +135,44 @@ void launch_pair_u(qh_state_s *h, uint64_t nwork, int p, const qh::BitIns &ins, 
     hipLaunchKernelGGL((qh::k_pair<R, U, true, NT>), dim3(grid), dim3(256), 0, h->stream,
                        (A *)h->d_psi, nwork, p, ins, to_gate<R>(g), lowpred);
 }
+// Launch shapes of the per-gate kernels, chosen by measurement (tools/membench/pairbench.hip, profiles/r04/):
+// QH_GATE_SHAPE=0 keeps the round-3 shape everywhere (one item per thread, 256-thread blocks) for A/B runs.
+int gate_shape() { static int v = env_int("QH_GATE_SHAPE", 1); return v; }
+int log2_u64(uint64_t v) { int g = 0; while ((1ull << g) < v) ++g; return g; }
+bool tile_fits(uint64_t nwork, int per_block) {     // full tiles only (DPP partner fetch and the block rotation need them)
+  return nwork >= (uint64_t)per_block && nwork % per_block == 0 && ((nwork / per_block) & (nwork / per_block - 1)) == 0 &&
+         nwork / per_block < (1ull << 31);
+}
+
+template <typename R, int U, int WPB>
+void launch_pair_tile(qh_state_s *h, uint64_t nwork, int p, const qh::BitIns &ins, const double g[8], uint32_t lowpred) {
+  using A = typename qh::AmpT<R>::type;
+  const uint64_t blocks = nwork / (64 * U * WPB);
+  hipLaunchKernelGGL((qh::k_pair_tile<R, U, WPB, 3>), dim3((unsigned)blocks), dim3(64 * WPB), 0, h->stream, (A *)h->d_psi, p, ins,
+                     to_gate<R>(g), lowpred, log2_u64(blocks));
+}
+template <typename R, int P>
+void launch_pair_line(qh_state_s *h, uint64_t namps, const qh::BitIns &ins1, const double g[8], uint32_t lowpred) {
+  using A = typename qh::AmpT<R>::type;
+  const uint64_t blocks = namps / (64 * 8 * 4);
+  hipLaunchKernelGGL((qh::k_pair_line<R, P, 8, 4, 3>), dim3((unsigned)blocks), dim3(256), 0, h->stream, (A *)h->d_psi, ins1,
+                     to_gate<R>(g), lowpred, log2_u64(blocks));
+}
+
+// `ins` enumerates pairs (a zero inserted at p); `ins1` the amplitudes of the same set (no zero at p)
 template <typename R>
-void launch_pair(qh_state_s *h, uint64_t nwork, int p, const qh::BitIns &ins, const double g[8],
+void launch_pair(qh_state_s *h, uint64_t nwork, int p, const qh::BitIns &ins, const qh::BitIns &ins1, const double g[8],
                  uint32_t lowpred) {
+  if (gate_shape() && gate_nt()) {
+    if (p < 3 && tile_fits(2 * nwork, 64 * 8 * 4)) {
+      if (p == 0) launch_pair_line<R, 0>(h, 2 * nwork, ins1, g, lowpred);
+      else if (p == 1) launch_pair_line<R, 1>(h, 2 * nwork, ins1, g, lowpred);
+      else launch_pair_line<R, 2>(h, 2 * nwork, ins1, g, lowpred);
+      return;
+    }
+    if (p >= 3 && p <= 8 && tile_fits(nwork, 64 * 8 * 4)) return launch_pair_tile<R, 8, 4>(h, nwork, p, ins, g, lowpred);
+    if (p >= 20 && p <= 25 && tile_fits(nwork, 64 * 16 * 2)) return launch_pair_tile<R, 16, 2>(h, nwork, p, ins, g, lowpred);
+  }
   const int u = gate_u();
   if (gate_nt()) {
     if (u >= 4) launch_pair_u<R, 4, true>(h, nwork, p, ins, g, lowpred);
@@ -164,6 +200,13 @@ void launch_diag_u(qh_state_s *h, uint64_t nwork, int sel, const qh::BitIns &ins
 template <typename R>
 void launch_diag(qh_state_s *h, uint64_t nwork, int sel, const qh::BitIns &ins, double f0r, double f0i,
                  double f1r, double f1i, uint32_t lowpred = 0) {
+  using A = typename qh::AmpT<R>::type;
+  if (gate_shape() && gate_nt() && tile_fits(nwork, 64 * 8 * 4)) {
+    const uint64_t blocks = nwork / (64 * 8 * 4);
+    hipLaunchKernelGGL((qh::k_diag_tile<R, 8, 4, 3>), dim3((unsigned)blocks), dim3(256), 0, h->stream, (A *)h->d_psi, sel, ins,
+                       (R)f0r, (R)f0i, (R)f1r, (R)f1i, lowpred, log2_u64(blocks));
+    return;
+  }
   const int u = gate_u() * 2;  // a diagonal work item is one amplitude, a pair item two
   if (gate_nt()) {
     if (u >= 4) launch_diag_u<R, 4, true>(h, nwork, sel, ins, f0r, f0i, f1r, f1i, lowpred);
@@ -249,9 +292,9 @@ int launch_single(qh_state_s *h, const qh::GateRec &r) {
   }
   const uint64_t nwork = 1ull << (h->nloc - nc - 1);
   if (!h->dry) {
-    const qh::BitIns ins = make_ins(cm, r.tgt);
-    if (h->bw == 128) launch_pair<double>(h, nwork, r.tgt, ins, g, lowpred);
-    else launch_pair<float>(h, nwork, r.tgt, ins, g, lowpred);
+    const qh::BitIns ins = make_ins(cm, r.tgt), ins1 = make_ins(cm, -1);
+    if (h->bw == 128) launch_pair<double>(h, nwork, r.tgt, ins, ins1, g, lowpred);
+    else launch_pair<float>(h, nwork, r.tgt, ins, ins1, g, lowpred);
   }
   h->stats.kernels_launched++;
   h->stats.bytes_algorithmic += (1ull << (h->nloc - nc_all - 1)) * 2 * ab * 2;
@@ -272,6 +315,51 @@ int use_device(qh_state_s *h) {
   if (h->dry) return QH_OK;
   HIP_TRY(hipSetDevice(h->device));
   return QH_OK;
+}
+
+// Host waits.  A handle whose communicator has several ranks may wait for work that depends on OTHER processes (a
+// grouped send/recv completes only when every peer has posted its half): if a peer is missing, or the ranks disagree
+// about a round, a plain hipStreamSynchronize never returns.  Such handles poll instead and give up after
+// QH_COMM_TIMEOUT_MS (default 300 s): QH_ERR_COMM, the handle poisoned -- an error line instead of a hung job.
+int comm_timeout_ms() {
+  static int v = env_int("QH_COMM_TIMEOUT_MS", 300000);
+  return v;
+}
+bool watched(const qh_state_s *h) { return h->comm && h->comm->nranks > 1 && !h->comm->custom && !h->comm->dry; }
+template <typename Query> int poll_until_done(qh_state_s *h, Query query, const char *what) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 0;; ++spins) {
+    const hipError_t e = query();
+    if (e == hipSuccess) return QH_OK;
+    if (e != hipErrorNotReady) {
+      (void)hipGetLastError();
+      return fail(QH_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+    }
+    if (spins > 2000) {
+      const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      if (ms > comm_timeout_ms()) {
+        h->poisoned = true;
+        return fail(QH_ERR_COMM, "%s: rank %d of %d still waiting after %.0f s (QH_COMM_TIMEOUT_MS): a peer is missing or the "
+                    "ranks disagree about an exchange; the state of this handle is undefined", what, h->comm->rank, h->comm->nranks, ms * 1e-3);
+      }
+      struct timespec ts = {0, 50000};
+      nanosleep(&ts, nullptr);
+    }
+  }
+}
+int wait_stream(qh_state_s *h, hipStream_t s, const char *what) {
+  if (!watched(h)) {
+    HIP_TRY(hipStreamSynchronize(s));
+    return QH_OK;
+  }
+  return poll_until_done(h, [&] { return hipStreamQuery(s); }, what);
+}
+int wait_event(qh_state_s *h, hipEvent_t e, const char *what) {
+  if (!watched(h)) {
+    HIP_TRY(hipEventSynchronize(e));
+    return QH_OK;
+  }
+  return poll_until_done(h, [&] { return hipEventQuery(e); }, what);
 }
 
 // Sweeps may re-lay the state out into a second buffer (planner.h, Planner::relayout) when the handle owns its
@@ -402,7 +490,7 @@ int flush_impl(qh_state_s *h, qh::SlabIO *split = nullptr) {
       for (int b = 0; b < h->nglob; ++b)
         if (h->perm[b] < h->nloc) h->perm[b] = final_pos[h->perm[b]];
     }
-    if (!h->dry) qh::wait_all_arrivals(arr, h->stream);   // (a flush that planned no sweep)
+    qh::wait_all_arrivals(arr, h->stream);   // (a flush that planned no sweep)
     if (h->comm) h->comm->stats.sweeps_overlapped += io->sweeps_overlapped;
     if (rc != QH_OK && h->stats.kernels_launched == launched0) return rc;   // nothing ran: queue kept
     if (rc == QH_OK) rc = check_launch(h);
@@ -660,6 +748,7 @@ int qh_create_dry(int nbits, int bit_width, qh_handle *out) {
 
 int qh_destroy(qh_handle h) {
   if (!h) return QH_OK;
+  if (h->dry) (void)qh_comm_destroy(h);
   if (!h->dry) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
@@ -688,6 +777,7 @@ int qh_set_shard(qh_handle h, int nbits_global, uint64_t shard_index) {
                 (unsigned long long)shard_index, nbits_global - h->nloc);
   h->nglob = nbits_global;
   h->shard = shard_index;
+  h->sweep.plans.clear();   // cached plans were made for another shard geometry
   return QH_OK;
 }
 
@@ -848,8 +938,7 @@ int qh_upload(qh_handle h, const void *host, uint64_t offset, uint64_t count) {
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync((char *)h->d_psi + offset * h->amp_bytes(), host, count * h->amp_bytes(),
                          hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  return QH_OK;
+  return wait_stream(h, h->stream, "qh_upload");
 }
 
 int qh_download(qh_handle h, void *host, uint64_t offset, uint64_t count) {
@@ -861,8 +950,7 @@ int qh_download(qh_handle h, void *host, uint64_t offset, uint64_t count) {
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(host, (const char *)h->d_psi + offset * h->amp_bytes(),
                          count * h->amp_bytes(), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  return QH_OK;
+  return wait_stream(h, h->stream, "qh_download");
 }
 
 int qh_amplitude(qh_handle h, uint64_t logical_index, double out[2]) {
@@ -877,11 +965,11 @@ int qh_amplitude(qh_handle h, uint64_t logical_index, double out[2]) {
   const uint64_t li = phys & h->local_mask();
   if (h->bw == 128) {
     HIP_TRY(hipMemcpyAsync(out, (const char *)h->d_psi + li * 16, 16, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    if ((rc = wait_stream(h, h->stream, "qh_amplitude"))) return rc;
   } else {
     float f[2];
     HIP_TRY(hipMemcpyAsync(f, (const char *)h->d_psi + li * 8, 8, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    if ((rc = wait_stream(h, h->stream, "qh_amplitude"))) return rc;
     out[0] = f[0];
     out[1] = f[1];
   }
@@ -950,8 +1038,7 @@ int qh_sync(qh_handle h) {
   HIP_TRY(hipSetDevice(h->device));
   int rc = flush_impl(h);
   if (rc) return rc;
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  return QH_OK;
+  return wait_stream(h, h->stream, "qh_sync");
 }
 
 int qh_set_relayout(qh_handle h, int on, int *actual) {
@@ -987,7 +1074,7 @@ int qh_norm2(qh_handle h, double *out) {
     hipLaunchKernelGGL(qh::k_norm2<float>, dim3(grid), dim3(256), 0, h->stream,
                        (const float2 *)h->d_psi, n, 0ull, 0ull, h->d_red);
   HIP_TRY(hipMemcpyAsync(out, h->d_red, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  if ((rc = wait_stream(h, h->stream, "reader"))) return rc;
   return QH_OK;
 }
 
@@ -1019,7 +1106,7 @@ int qh_prob_bit_value(qh_handle h, int logical_bit, int value, double *p) {
     hipLaunchKernelGGL(qh::k_norm2<float>, dim3(grid), dim3(256), 0, h->stream,
                        (const float2 *)h->d_psi, n, mask, want, h->d_red);
   HIP_TRY(hipMemcpyAsync(p, h->d_red, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  if ((rc = wait_stream(h, h->stream, "reader"))) return rc;
   return QH_OK;
 }
 
@@ -1042,7 +1129,7 @@ int qh_argmax(qh_handle h, uint64_t *phys_index, double *prob) {
   std::vector<uint64_t> bi(grid);
   HIP_TRY(hipMemcpyAsync(bp.data(), h->d_red, grid * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipMemcpyAsync(bi.data(), h->d_redi, grid * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  if ((rc = wait_stream(h, h->stream, "reader"))) return rc;
   double best = -1.0;
   uint64_t idx = 0;
   for (unsigned k = 0; k < grid; ++k)
@@ -1118,7 +1205,7 @@ int qh_timer_end(qh_handle h, float *ms) {
   int rc = flush_impl(h);
   if (rc) return rc;
   HIP_TRY(hipEventRecord(h->ev1, h->stream));
-  HIP_TRY(hipEventSynchronize(h->ev1));
+  if ((rc = wait_event(h, h->ev1, "qh_timer_end"))) return rc;
   HIP_TRY(hipEventElapsedTime(ms, h->ev0, h->ev1));
   return QH_OK;
 }
@@ -1140,7 +1227,10 @@ int qh_timer_laps(qh_handle h, float *ms, int cap, int *count) {
   if (!h || !count || h->dry) return fail(QH_ERR_ARG, "null/dry");
   HIP_TRY(hipSetDevice(h->device));
   const int n = h->laps_used > 0 ? (int)h->laps_used - 1 : 0;
-  if (h->laps_used) HIP_TRY(hipEventSynchronize(h->laps[h->laps_used - 1]));
+  if (h->laps_used) {
+    const int rc = wait_event(h, h->laps[h->laps_used - 1], "qh_timer_laps");
+    if (rc) return rc;
+  }
   for (int k = 0; k < n && ms && k < cap; ++k) HIP_TRY(hipEventElapsedTime(&ms[k], h->laps[k], h->laps[k + 1]));
   *count = n;
   h->laps_used = 0;
@@ -1315,16 +1405,44 @@ int verify_geometry(qh_state_s *h, uint64_t sig) {
                     "planned different sweeps or layouts", c->rank, (unsigned long long)sig, peers[k], (unsigned long long)theirs[k]);
     return QH_OK;
   }
-  if (!env_int("QH_EXCHANGE_VERIFY", 0)) return QH_OK;
-  double v[4] = {(double)(sig >> 32), (double)(sig & 0xffffffffu), -(double)(sig >> 32), -(double)(sig & 0xffffffffu)};
-  HIP_TRY(hipMemcpyAsync(h->d_red, v, sizeof v, hipMemcpyHostToDevice, h->stream));
-  NCCL_TRY(qh::rccl().AllReduce(h->d_red, h->d_red, 4, ncclDouble, ncclMax, c->nccl, h->stream));
-  double w[4];
-  HIP_TRY(hipMemcpyAsync(w, h->d_red, sizeof w, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  // RCCL: every geometry this communicator has not compared yet (QH_EXCHANGE_VERIFY=1: every exchange, =0: never).
+  // The all-reduce runs on the EXCHANGE stream -- it does not wait for the sweeps queued on the compute stream --
+  // and the host waits for it: once per distinct geometry (a loop over one circuit cycles through a few layouts).
+  static const int mode = env_int("QH_EXCHANGE_VERIFY", -1);
+  if (mode == 0) return QH_OK;
+  if (mode < 0 && std::find(c->verified.begin(), c->verified.end(), sig) != c->verified.end()) return QH_OK;
+  if (!c->d_sig) {
+    HIP_TRY(hipMalloc((void **)&c->d_sig, 4 * sizeof(double)));
+    HIP_TRY(hipHostMalloc((void **)&c->h_sig, 8 * sizeof(double), hipHostMallocDefault));
+  }
+  double *v = c->h_sig, *w = c->h_sig + 4;
+  v[0] = (double)(sig >> 32); v[1] = (double)(sig & 0xffffffffu); v[2] = -v[0]; v[3] = -v[1];
+  HIP_TRY(hipMemcpyAsync(c->d_sig, v, 4 * sizeof(double), hipMemcpyHostToDevice, c->xstream));
+  NCCL_TRY(qh::rccl().AllReduce(c->d_sig, c->d_sig, 4, ncclDouble, ncclMax, c->nccl, c->xstream));
+  HIP_TRY(hipMemcpyAsync(w, c->d_sig, 4 * sizeof(double), hipMemcpyDeviceToHost, c->xstream));
+  const int rc = wait_stream(h, c->xstream, "exchange geometry check (all-reduce of the signature)");
+  if (rc) return rc;
   if (w[0] != -w[2] || w[1] != -w[3])
-    return fail(QH_ERR_COMM, "exchange geometry differs between ranks (signature of rank %d: %016llx)", c->rank, (unsigned long long)sig);
+    return fail(QH_ERR_COMM, "exchange geometry differs between ranks (signature of rank %d: %016llx; largest / smallest halves seen: "
+                "%08x%08x / %08x%08x): the ranks planned different sweeps or layouts, or run with different planner switches "
+                "(QH_* environment) or builds", c->rank, (unsigned long long)sig, (unsigned)w[0], (unsigned)w[1], (unsigned)-w[2], (unsigned)-w[3]);
+  if (c->verified.size() >= 256) c->verified.erase(c->verified.begin());
+  c->verified.push_back(sig);
   return QH_OK;
+}
+
+// What must be equal on every rank besides the geometry itself: the planner's switches and the build.
+uint64_t env_build_hash() {
+  std::string s = qh::planner_env_signature();
+  for (const char *n : {"QH_EXCHANGE_SLAB_BITS", "QH_EXCHANGE_PACK", "QH_RELAYOUT", "QH_LTAB_LDS", "QH_SWEEP_BLOCK_WAVES", "QH_SUPERS_PER_BLOCK"}) {
+    const char *e = getenv(n);
+    s += e ? e : "-";
+    s += ';';
+  }
+  s += __DATE__ " " __TIME__;
+  uint64_t hsh = 0xcbf29ce484222325ull;
+  for (unsigned char ch : s) { hsh ^= ch; hsh *= 0x100000001b3ull; }
+  return hsh;
 }
 
 // The exchange proper.  `moves`: block value blk of the g LOGICAL local bits [base, base+g) goes to `peer`,
@@ -1338,14 +1456,19 @@ int do_exchange(qh_state_s *h, const std::vector<qh::BlockMove> &moves, int base
   for (int k = 0; k < gbits; ++k)
     if (h->perm[base + k] >= nloc) return fail(QH_ERR_BAD_QUBIT, "exchange bit %d is not a local bit of this shard", base + k);
   if (moves.size() > (size_t)qh::kMaxXferMoves) return fail(QH_ERR_ARG, "too many peers");
-  HIP_TRY(hipSetDevice(h->device));
-  close_timing(c);
+  if (h->poisoned) return fail(QH_ERR_HIP, "the state of this handle is undefined (an earlier sweep or exchange failed); re-initialise it");
+  const bool dry = h->dry;
+  if (!dry) {
+    HIP_TRY(hipSetDevice(h->device));
+    close_timing(c);
+  }
   // 1. the queued gates, the last sweep cut into slabs
   qh::SlabIO io;
   io.split_last = true;
   for (int k = 0; k < gbits; ++k) io.avoid |= 1ull << h->perm[base + k];   // (layout before the flush; run_fused follows the moves)
-  io.want_bits = env_int("QH_EXCHANGE_SLAB_BITS", 3);
+  io.want_bits = std::max(0, std::min(env_int("QH_EXCHANGE_SLAB_BITS", qh::kMaxSlabBits), qh::kMaxSlabBits));   // (UnitPerm::slab_pos)
   c->pool_used = 0;   // (arrivals of the previous exchange are waited for by this flush)
+  const uint64_t sweeps0 = h->stats.sweeps;
   int rc = flush_impl(h, &io);
   if (rc) return rc;
   // 2. where the blocks' bits live now
@@ -1368,7 +1491,9 @@ int do_exchange(qh_state_s *h, const std::vector<qh::BlockMove> &moves, int base
   }
   const int K = (int)slab_vals.size();
   hipEvent_t all_done = nullptr;
-  if (io.slab_done.empty() || std::find(io.slab_done.begin(), io.slab_done.end(), nullptr) != io.slab_done.end()) {
+  if (dry) {
+    io.slab_done.assign(K, nullptr);
+  } else if (io.slab_done.empty() || std::find(io.slab_done.begin(), io.slab_done.end(), nullptr) != io.slab_done.end()) {
     all_done = c->event();
     if (!all_done) return fail(QH_ERR_HIP, "hipEventCreate failed");
     HIP_TRY(hipEventRecord(all_done, h->stream));
@@ -1398,6 +1523,28 @@ int do_exchange(qh_state_s *h, const std::vector<qh::BlockMove> &moves, int base
     for (int b = 0; b < h->nglob; ++b) mix((uint64_t)h->perm[b]);
     mix(slab_mask); mix((uint64_t)chunk_bits); mix(nchunks); mix(packed); mix((uint64_t)K); mix(blockbits); mix((uint64_t)base); mix((uint64_t)gbits);
     for (uint64_t v : slab_vals) mix(v);
+    mix((uint64_t)np); mix((uint64_t)h->bw); mix(env_build_hash());
+    qh_xgeom &G = c->last_geom;
+    G.signature = sig;
+    G.slab_mask = slab_mask;
+    G.block_bits = blockbits;
+    G.rounds_per_slab = nchunks;
+    G.staging_bytes = (uint64_t)(packed ? 4 : 2) * np * n * ab;
+    G.slabs = (uint32_t)K;
+    G.chunk_bits = (uint32_t)chunk_bits;
+    G.packed = packed ? 1 : 0;
+    G.peers = (uint32_t)np;
+    G.sweeps_before = (uint32_t)(h->stats.sweeps - sweeps0);
+    G.last_sweep_split = io.split_done ? 1 : 0;
+    if (dry) {     // planner-only handle: the decisions are on record, the next flush sees the arrivals it would see
+      for (int k = 0; k < K; ++k) c->arrivals.push_back(qh::Arrival{slab_mask, slab_vals[k], nullptr});
+      c->stats.exchanges++;
+      c->stats.slabs += K;
+      c->stats.rounds += (uint64_t)K * nchunks;
+      c->stats.rounds_packed += packed ? (uint64_t)K * nchunks : 0;
+      c->stats.bytes_sent += (uint64_t)np * (1ull << (nloc - gbits)) * ab;
+      return QH_OK;
+    }
     rc = verify_geometry(h, sig);
     if (rc) return rc;
   }
@@ -1598,9 +1745,35 @@ int qh_comm_init_custom(qh_handle h, int nranks, int rank, qh_round_fn fn, void 
   return QH_OK;
 }
 
+int qh_comm_init_dry(qh_handle h, int nranks, int rank) {
+  if (!h || !h->dry) return fail(QH_ERR_ARG, "qh_comm_init_dry is for planner-only handles (qh_create_dry)");
+  if (h->comm) return fail(QH_ERR_ARG, "handle already has a communicator");
+  if (nranks < 1 || (nranks & (nranks - 1)) || rank < 0 || rank >= nranks)
+    return fail(QH_ERR_ARG, "nranks %d must be a power of two, rank %d inside it", nranks, rank);
+  if (nranks > qh::kMaxXferMoves + 1) return fail(QH_ERR_ARG, "at most %d ranks", qh::kMaxXferMoves + 1);
+  auto *c = new qh::Comm;
+  c->nranks = nranks;
+  c->rank = rank;
+  c->dry = true;
+  h->comm = c;
+  return QH_OK;
+}
+
+int qh_exchange_geometry(qh_handle h, qh_xgeom *out) {
+  if (!h || !out) return fail(QH_ERR_ARG, "null");
+  if (!h->comm) return fail(QH_ERR_ARG, "no communicator on this handle");
+  *out = h->comm->last_geom;
+  return QH_OK;
+}
+
 int qh_comm_destroy(qh_handle h) {
   if (!h || !h->comm) return QH_OK;
   qh::Comm *c = h->comm;
+  if (c->dry) {
+    delete c;
+    h->comm = nullptr;
+    return QH_OK;
+  }
   (void)hipSetDevice(h->device);
   if (c->pstream) (void)hipStreamSynchronize(c->pstream);
   if (c->xstream) (void)hipStreamSynchronize(c->xstream);
@@ -1610,6 +1783,8 @@ int qh_comm_destroy(qh_handle h) {
   if (c->t0) (void)hipEventDestroy(c->t0);
   if (c->t1) (void)hipEventDestroy(c->t1);
   if (c->staging) (void)hipFree(c->staging);
+  if (c->d_sig) (void)hipFree(c->d_sig);
+  if (c->h_sig) (void)hipHostFree(c->h_sig);
   if (c->h_send) (void)hipHostFree(c->h_send);
   if (c->h_recv) (void)hipHostFree(c->h_recv);
   if (c->xstream) (void)hipStreamDestroy(c->xstream);
@@ -1645,9 +1820,13 @@ int qh_exchange_loopback(qh_handle h, int local_bit, uint64_t chunk_amps) {
 }
 
 int qh_exchange_wait(qh_handle h) {
-  if (!h || !h->comm) return QH_OK;
+  if (!h || !h->comm || h->comm->dry) return QH_OK;
   HIP_TRY(hipSetDevice(h->device));
-  for (const qh::Arrival &a : h->comm->arrivals) HIP_TRY(hipEventSynchronize(a.ev));
+  for (const qh::Arrival &a : h->comm->arrivals) {
+    if (!a.ev) continue;
+    const int rc = wait_event(h, a.ev, "qh_exchange_wait");
+    if (rc) return rc;
+  }
   close_timing(h->comm);
   return QH_OK;
 }
@@ -1658,8 +1837,10 @@ int qh_exchange_stats(qh_handle h, qh_xstats *out) {
     memset(out, 0, sizeof *out);
     return QH_OK;
   }
-  HIP_TRY(hipSetDevice(h->device));
-  close_timing(h->comm);
+  if (!h->comm->dry) {
+    HIP_TRY(hipSetDevice(h->device));
+    close_timing(h->comm);
+  }
   *out = h->comm->stats;
   return QH_OK;
 }
@@ -1674,7 +1855,7 @@ int qh_comm_allreduce_sum(qh_handle h, double *inout, int count) {
   HIP_TRY(hipMemcpyAsync(h->d_red, inout, count * sizeof(double), hipMemcpyHostToDevice, h->stream));
   NCCL_TRY(qh::rccl().AllReduce(h->d_red, h->d_red, (size_t)count, ncclDouble, ncclSum, h->comm->nccl, h->stream));
   HIP_TRY(hipMemcpyAsync(inout, h->d_red, count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  if ((rc = wait_stream(h, h->stream, "reader"))) return rc;
   return QH_OK;
 }
 

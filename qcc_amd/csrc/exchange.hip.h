@@ -128,6 +128,7 @@ struct Arrival {
 
 struct Comm {
   int nranks = 0, rank = 0;
+  bool dry = false;                  // planner-only handle (qh_comm_init_dry): geometry is decided and recorded, nothing moves
   ncclComm_t nccl = nullptr;
   qh_round_fn custom = nullptr;      // host-staged transport (tests / no peer access)
   void *custom_user = nullptr;
@@ -144,6 +145,9 @@ struct Comm {
   bool timing_open = false;
   std::vector<Arrival> arrivals;     // consumed by the next flush
   qh_xstats stats{};
+  qh_xgeom last_geom{};              // how the last exchange was cut (qh_exchange_geometry)
+  std::vector<uint64_t> verified;    // geometry signatures the ranks have already compared (RCCL transport)
+  double *d_sig = nullptr, *h_sig = nullptr;   // 4 doubles in HBM / 8 pinned: the signature all-reduce of verify_geometry
 
   hipEvent_t event() {
     if (pool_used == pool.size()) {

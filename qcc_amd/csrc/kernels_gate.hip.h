@@ -28,7 +28,8 @@
 
 namespace qh {
 
-constexpr int kMaxIns = 14;   // (the planner folds at most 12 into a plan: two are left for the slab bits of a launch around an exchange)
+constexpr int kMaxIns = 15;   // 12 bits a plan may fold into the tile enumeration + 3 slab bits of a launch around an exchange
+                              // (planner.h kMaxInsertBits + kMaxSlabBits; static_assert in kernels_sweep.hip.h)
 
 // Sorted (ascending) list of bit positions at which a bit is inserted into a
 // dense work-item counter to form an amplitude index; `ones` has the inserted
@@ -161,6 +162,122 @@ __global__ __launch_bounds__(256) void k_diag(typename AmpT<R>::type *__restrict
         st_amp<NT>(&psi[idx[u]], t);
       }
     }
+  }
+}
+
+// ---- wave-tile shapes (round 4) -----------------------------------------------------------------
+// Chosen by measurement (tools/membench/pairbench.hip, profiles/r04/pairbench.txt; in place, 2^30 complex128):
+//   * a wave owns 64*U consecutive work items (U KiB contiguous per stream), all its loads are issued before the
+//     first result is needed, blocks of WPB waves take consecutive tiles, and the block index is rotated by 3 bits
+//     (consecutive workgroups stream from 8 far-apart regions of the state: as k_sweep does);
+//   * one-stream kernels (diagonal gates: the touched quarter / half of the state): U = 8, four waves -- 5.6-6.6 TB/s
+//     against 5.0-5.9 for one item per thread;
+//   * pair kernels: the same shape wins for target bits 3..8 (6.0-6.2 vs 5.9 TB/s), U = 16 / two waves for bits
+//     20..25 (5.7-6.0 vs 5.5); elsewhere the round-3 shape (one pair per thread, 256-thread blocks) stays;
+//   * a target INSIDE the 128-byte line (bits 0..2 of complex128, 0..3 of complex64) pairs amplitudes of one wave
+//     row: every thread then loads ONE amplitude (whole lines, each fetched once) and takes its partner from the
+//     neighbouring lane by DPP moves -- the two-loads-per-thread enumeration fetched every line twice (5.4 TB/s).
+// (the launcher passes blk_bits = 0 for grids too small to rotate)
+template <int ROT> __device__ __forceinline__ uint64_t rot_block(uint64_t bi, int blk_bits) {
+  if (ROT && blk_bits > ROT) bi = ((bi >> ROT) | (bi << (blk_bits - ROT))) & ((1ull << blk_bits) - 1);
+  return bi;
+}
+
+template <typename R, int U, int WPB, int ROT>
+__global__ __launch_bounds__(64 * WPB) void k_pair_tile(typename AmpT<R>::type *__restrict__ psi, int p, BitIns ins,
+                                                         Gate2<R> g, uint32_t lowpred, int blk_bits) {
+  using A = typename AmpT<R>::type;
+  const uint64_t bi = rot_block<ROT>(blockIdx.x, blk_bits);
+  const uint64_t base = ((bi * WPB + (threadIdx.x >> 6)) * U) * 64ull + (threadIdx.x & 63);
+  const uint64_t q2 = 1ull << p;
+  A a[U], b[U];
+  uint64_t idx[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) idx[u] = expand_index(base + 64ull * u, ins);
+#pragma unroll
+  for (int u = 0; u < U; ++u) a[u] = ld_amp<true>(&psi[idx[u]]);
+#pragma unroll
+  for (int u = 0; u < U; ++u) b[u] = ld_amp<true>(&psi[idx[u] | q2]);
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    if (((uint32_t)idx[u] & lowpred) == lowpred) butterfly<R, A>(g, a[u], b[u]);
+    st_amp<true>(&psi[idx[u]], a[u]);
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) st_amp<true>(&psi[idx[u] | q2], b[u]);
+}
+
+template <typename R, int U, int WPB, int ROT>
+__global__ __launch_bounds__(64 * WPB) void k_diag_tile(typename AmpT<R>::type *__restrict__ psi, int sel, BitIns ins,
+                                                         R f0r, R f0i, R f1r, R f1i, uint32_t lowpred, int blk_bits) {
+  using A = typename AmpT<R>::type;
+  const uint64_t bi = rot_block<ROT>(blockIdx.x, blk_bits);
+  const uint64_t base = ((bi * WPB + (threadIdx.x >> 6)) * U) * 64ull + (threadIdx.x & 63);
+  A a[U];
+  uint64_t idx[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) idx[u] = expand_index(base + 64ull * u, ins);
+#pragma unroll
+  for (int u = 0; u < U; ++u) a[u] = ld_amp<true>(&psi[idx[u]]);
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const bool hi = sel < 0 || ((idx[u] >> sel) & 1ull);
+    const bool on = ((uint32_t)idx[u] & lowpred) == lowpred;
+    const R fr = on ? (hi ? f1r : f0r) : (R)1, fi = on ? (hi ? f1i : f0i) : (R)0;
+    A t;
+    t.x = fr * a[u].x - fi * a[u].y;
+    t.y = fr * a[u].y + fi * a[u].x;
+    st_amp<true>(&psi[idx[u]], t);
+  }
+}
+
+// value of lane (l ^ (1 << P)), P = 0..3, by DPP moves (no LDS): quad_perm for bits 0 and 1, row_half_mirror +
+// quad_perm for bit 2, row_ror:8 for bit 3
+template <int P> __device__ __forceinline__ int lane_xor_i32(int v) {
+  if constexpr (P == 0) return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);        // quad_perm:[1,0,3,2]
+  else if constexpr (P == 1) return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);   // quad_perm:[2,3,0,1]
+  else if constexpr (P == 2) {
+    const int t = __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);                    // row_half_mirror: l -> l ^ 7
+    return __builtin_amdgcn_update_dpp(0, t, 0x1B, 0xf, 0xf, false);                            // quad_perm:[3,2,1,0]: ^ 3
+  } else return __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, false);                      // row_ror:8: l ^ 8 within 16
+}
+template <int P> __device__ __forceinline__ double lane_xor(double v) {
+  const long long w = __double_as_longlong(v);
+  const int lo = lane_xor_i32<P>((int)(w & 0xffffffffll)), hi = lane_xor_i32<P>((int)(w >> 32));
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+template <int P> __device__ __forceinline__ float lane_xor(float v) {
+  return __int_as_float(lane_xor_i32<P>(__float_as_int(v)));
+}
+
+// Dense / anti-diagonal 2x2 on a target bit P INSIDE the line: work item = one AMPLITUDE (controls inserted as ones,
+// no zero at P); lane l and lane l ^ 2^P hold the pair.
+template <typename R, int P, int U, int WPB, int ROT>
+__global__ __launch_bounds__(64 * WPB) void k_pair_line(typename AmpT<R>::type *__restrict__ psi, BitIns ins, Gate2<R> g,
+                                                         uint32_t lowpred, int blk_bits) {
+  using A = typename AmpT<R>::type;
+  const uint64_t bi = rot_block<ROT>(blockIdx.x, blk_bits);
+  const uint64_t base = ((bi * WPB + (threadIdx.x >> 6)) * U) * 64ull + (threadIdx.x & 63);
+  const bool hi = (threadIdx.x >> P) & 1u;      // (index bit P == lane bit P: the 64 items of a wave row are consecutive indices)
+  // new = ca * own + cb * partner: row 0 of the matrix on the pair's low element, row 1 on the high one
+  const R car = hi ? g.g3r : g.g0r, cai = hi ? g.g3i : g.g0i, cbr = hi ? g.g2r : g.g1r, cbi = hi ? g.g2i : g.g1i;
+  A a[U];
+  uint64_t idx[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) idx[u] = expand_index(base + 64ull * u, ins);
+#pragma unroll
+  for (int u = 0; u < U; ++u) a[u] = ld_amp<true>(&psi[idx[u]]);
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    A q;
+    q.x = lane_xor<P>(a[u].x);
+    q.y = lane_xor<P>(a[u].y);
+    A t = a[u];
+    if (((uint32_t)idx[u] & lowpred) == lowpred) {
+      t.x = (car * a[u].x - cai * a[u].y) + (cbr * q.x - cbi * q.y);
+      t.y = (car * a[u].y + cai * a[u].x) + (cbr * q.y + cbi * q.x);
+    }
+    st_amp<true>(&psi[idx[u]], t);
   }
 }
 

@@ -65,7 +65,8 @@ constexpr int kMaxRegBits = 6; // complex128: 5 (32 amplitudes = 128 VGPRs of da
 inline int max_reg_bits(int bw) { return bw == 128 ? 5 : 6; }
 constexpr int kMaxWaveBits = 2; // index bits selected by the wave id inside a workgroup ("super-tile", see OP_WSWAP)
 constexpr int kMaxSweepOps = 1024;
-constexpr int kMaxInsertBits = 12;  // <= kMaxIns of kernels_gate.hip.h (tile enumeration; slab launches add up to 3 more)
+constexpr int kMaxInsertBits = 12;  // bits a PLAN folds into the tile enumeration (fixed ones + register + movable lane + wave bits)
+constexpr int kMaxSlabBits = 3;     // a slab launch around an exchange fixes up to this many more: kMaxIns (kernels_gate.hip.h) = the sum
 
 enum : uint32_t { OP_DENSE_REG = 0, OP_DENSE_LANE = 1, OP_DIAG = 2,
                   OP_LSWAP = 3,    // lane bit tb (4|5) <-> register bit cm_reg (v_permlane swaps)
@@ -1181,6 +1182,28 @@ class Planner {
     }
     const double floor_cycles = env_int("QH_LDS_FLOOR", 2500);   // (read at every flush, like the other planner switches)
     LaneChoice ch;
+    // QH_LANE_LDS_BUDGET (cycles of the LDS pipe per tile): instead of all-or-nothing, move lane butterflies to the VALU
+    // only until the LDS pipe fits the budget, cheapest VALU alternative first -- lane bits 4 / 5 (v_permlane swap: +72
+    // VALU instructions), then the one-move DPP bits 0, 1, 3 (+128), last lane bit 2 (+256).  The sweeps of a layered
+    // circuit are bound by VALU issue, not by latency: every butterfly left on the (otherwise idle) LDS pipe is 128-256
+    // VALU instructions less per tile.
+    const int budget = env_int("QH_LANE_LDS_BUDGET", -1);
+    if (budget >= 0) {
+      int n45 = 0, n013 = 0, n2 = 0;
+      for (const SweepOp &o : sp.ops) {
+        if (o.kind != OP_DENSE_LANE || !(o.flags & (OPF_BFLY | OPF_REAL))) continue;
+        if (o.tb >= 4) n45 += (o.flags & OPF_BFLY) ? 1 : 0;
+        else if (one_step_dpp(o.tb)) n013++;
+        else n2++;
+      }
+      double over = lds - budget;
+      auto move = [&](int avail) { int k = 0; while (k < avail && over > 0) { ++k; over -= kLds; } return k; };
+      const int m45 = move(n45), m013 = move(n013), m2 = move(n2);
+      ch.lswap = m45;
+      ch.dpp01 = ch.real01 = m013;
+      ch.dpp23 = ch.real23 = m2;
+      return ch;
+    }
     if (lds > floor_cycles) ch.dpp01 = ch.dpp23 = ch.lswap = ch.real01 = ch.real23 = 1 << 20;
     return ch;
   }

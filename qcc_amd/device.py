@@ -64,13 +64,15 @@ class DeviceState:
   """Owns a qh_handle.  complex128 (bit_width=128) or complex64 (64)."""
 
   def __init__(self, nbits, bit_width=128, device=0, fusion=native.QH_FUSE_OFF, *,
-               device_ptr=None, stream=None, host_mapped=False):
+               device_ptr=None, stream=None, host_mapped=False, dry=False):
     self.lib = native.load()
     self.nbits = int(nbits)
     self.bit_width = int(bit_width)
     self.dtype = np.complex128 if bit_width == 128 else np.complex64
     h = ctypes.c_void_p()
-    if host_mapped:
+    if dry:        # planner-only handle (qh_create_dry): gates queue, plans and exchange geometry can be inspected, no device
+      native.check(self.lib.qh_create_dry(self.nbits, self.bit_width, ctypes.byref(h)))
+    elif host_mapped:
       native.check(self.lib.qh_create_host_mapped(self.nbits, self.bit_width, device, ctypes.byref(h)))
     elif device_ptr is None:
       native.check(self.lib.qh_create(self.nbits, self.bit_width, device, ctypes.byref(h)))
@@ -245,6 +247,16 @@ class DeviceState:
 
   def exchange_wait(self):
     native.check(self.lib.qh_exchange_wait(self.h))
+
+  def comm_init_dry(self, nranks, rank):
+    """Planner-only handles: qh_exchange_* decide slabs / rounds / path like rank `rank` of `nranks` would; nothing moves."""
+    native.check(self.lib.qh_comm_init_dry(self.h, int(nranks), int(rank)))
+
+  def exchange_geometry(self):
+    """How the last exchange was cut (qh_xgeom): equal on every rank by construction, compared before data moves."""
+    g = native.QhXGeom()
+    native.check(self.lib.qh_exchange_geometry(self.h, ctypes.byref(g)))
+    return g.as_dict()
 
   def exchange_stats(self):
     s = native.QhXStats()

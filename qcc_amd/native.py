@@ -98,6 +98,16 @@ class QhXStats(ctypes.Structure):
     return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class QhXGeom(ctypes.Structure):
+  """include/qcc_hip.h qh_xgeom: how the last exchange of a handle was cut (equal on every rank, or the exchange fails)."""
+  _fields_ = [('signature', _u64), ('slab_mask', _u64), ('block_bits', _u64), ('rounds_per_slab', _u64), ('staging_bytes', _u64),
+              ('slabs', ctypes.c_uint32), ('chunk_bits', ctypes.c_uint32), ('packed', ctypes.c_uint32), ('peers', ctypes.c_uint32),
+              ('sweeps_before', ctypes.c_uint32), ('last_sweep_split', ctypes.c_uint32)]
+
+  def as_dict(self):
+    return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
 # one round of the host-staged transport (include/qcc_hip.h: qh_round_fn)
 ROUND_FN = ctypes.CFUNCTYPE(ctypes.c_int, _vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(_vp),
                             ctypes.POINTER(_vp), _u64)
@@ -106,6 +116,8 @@ SIGNATURES.update({
     'qh_comm_unique_id': (_i32, [_vp]),
     'qh_comm_init': (_i32, [_vp, _i32, _i32, _vp]),
     'qh_comm_init_custom': (_i32, [_vp, _i32, _i32, ROUND_FN, _vp]),
+    'qh_comm_init_dry': (_i32, [_vp, _i32, _i32]),
+    'qh_exchange_geometry': (_i32, [_vp, ctypes.POINTER(QhXGeom)]),
     'qh_comm_destroy': (_i32, [_vp]),
     'qh_exchange_alltoall': (_i32, [_vp, _i32, _u64]),
     'qh_exchange_pair': (_i32, [_vp, _i32, _i32, _u64]),

@@ -27,23 +27,24 @@ The exchange itself runs BEHIND THE C-ABI (qh_exchange_alltoall / qh_exchange_pa
 qcc_amd/csrc/exchange.hip.h): ncclSend/ncclRecv on the engine's own exchange stream, landing
 copies on a third stream, and -- cut into slabs -- overlapped with the last sweep before and the
 first sweep after it on the compute stream (HIP events, no host wait).  This module only routes
-gates, keeps the logical->physical bit map and hands RCCL's unique id around through
-torch.distributed (control plane).  `self.exchange_path` says which path is live:
-  'rccl'        engine-native RCCL (default with the nccl backend),
-  'host-staged' engine-native rounds through a torch.distributed/gloo callback (several ranks
-                sharing one GPU: tests),
-  'torch-p2p'   torch.distributed.batch_isend_irecv on torch views of the shard -- the CPU test
-                double (gloo, `engine_factory`), or QCC_EXCHANGE=torch.
+gates (ShardRouter: pure Python, no torch), keeps the logical->physical bit map and hands RCCL's
+unique id around through torch.distributed (control plane).  ONE transport family: the engine's.
+`self.exchange_path` says how its rounds travel:
+  'rccl'        RCCL send/recv over xGMI (the nccl backend: one rank per GPU),
+  'host-staged' the same rounds carried by a torch.distributed/gloo callback (several ranks
+                sharing one GPU: tests; fabrics without peer access).
+If the transport cannot be set up on EVERY rank, ShardedState raises on every rank (bench.py turns
+that into a JSON line with "error"); there is no second data path to fall back to.
 
 The local engine is a qcc_amd.device.DeviceState that OWNS its shard (qh_create + qh_set_shard): it
 may then re-lay the shard out between its two buffers like a single-GPU handle does (relayout sweeps,
 planner.h), and the exchange follows the index bits wherever they are (packed rounds).  Every rank
 submits EVERY gate to its engine -- also the ones whose shard-bit control is 0 on this rank: the
 planner keeps those as ghosts, so that all ranks plan the same sweeps, tiles, slabs and layouts (an
-exchange needs them to agree; engine.hip verify_geometry checks it).  Only the torch-p2p double
-(QCC_EXCHANGE=torch, or CPU engines through `engine_factory`) works on a torch allocation and resolves
-shard-bit controls here.  Tests substitute a CPU engine and the gloo backend through `engine_factory`
-to exercise exactly this routing / bit-map code with world_size 2 and 4.
+exchange needs them to agree; engine.hip verify_geometry checks it before data moves).  Tests
+substitute an engine of the same interface (tests/fake_device.py NumpyShardEngine, host-staged rounds
+over gloo) through `engine_factory` to exercise exactly this routing / bit-map code with world sizes
+2 and 4; DryShard runs one rank's routing and PLANNING without any device or process group.
 """
 import math
 import os
@@ -53,69 +54,19 @@ import numpy as np
 NO_CTL = -(2 ** 31)
 
 
-def _is_diag(g4):
-  return g4[1] == 0 and g4[2] == 0
+class ShardRouter:
+  """The routing of a gate stream over the shard bits, as ONE rank does it: logical -> physical bit map, which
+  gates force an exchange, which local bits give way (Belady), the bookkeeping of the swaps.  Pure Python over an
+  engine object (qcc_amd.device.DeviceState or anything with its interface); no torch, no process group."""
 
-
-def _hip_engine_factory(nloc, local_rank, fusion, bit_width=128, torch_memory=False):
-  """(engine, flat real-valued torch view of the shard or None) on cuda:local_rank.  The engine owns its
-  shard unless `torch_memory` (the torch-p2p exchange needs torch views of it)."""
-  import torch
-  from qcc_amd import device
-  if not torch.cuda.is_available():
-    raise RuntimeError('torch sees no GPU.  If the engine library was loaded before torch was imported, two HIP '
-                       'runtimes are mapped (see qcc_amd.native._preload_torch_runtime): import torch first or '
-                       'launch through torchrun / set QCC_PRELOAD_TORCH=1')
-  torch.cuda.set_device(local_rank)
-  if not torch_memory:
-    return device.DeviceState(nloc, bit_width, device=local_rank, fusion=fusion), None
-  buf = torch.zeros(2 << nloc, dtype=torch.float64 if bit_width == 128 else torch.float32, device=f'cuda:{local_rank}')
-  eng = device.DeviceState(nloc, bit_width, device=local_rank, fusion=fusion, device_ptr=buf.data_ptr())
-  return eng, buf
-
-
-class ShardedState:
-  """State (complex128, or complex64 with bit_width=64) sharded by its top log2(P) physical index bits."""
-
-  def __init__(self, nbits, fusion=1, local_rank=None, *, engine_factory=None, backend=None,
-               chunk_amps=1 << 22, exchange='alltoall', bit_width=128):
-    import torch
-    import torch.distributed as dist
-    self.torch, self.dist = torch, dist
-    if not dist.is_initialized():
-      # QCC_DIST_BACKEND=gloo: several ranks on ONE GPU (tests of this layer); RCCL refuses that
-      backend = backend or os.environ.get('QCC_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
-      os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-      if 'RANK' not in os.environ and 'WORLD_SIZE' not in os.environ:   # not under torchrun: a world of one
-        os.environ.update(RANK='0', WORLD_SIZE='1')
-        os.environ.setdefault('MASTER_PORT', '29533')
-      kw = {}
-      if backend == 'nccl' and local_rank is not None:
-        torch.cuda.set_device(local_rank)
-        try:
-          kw['device_id'] = torch.device(f'cuda:{local_rank}')
-        except Exception:  # pylint: disable=broad-except
-          kw = {}
-      dist.init_process_group(backend=backend, **kw)
-    self.rank, self.world = dist.get_rank(), dist.get_world_size()
+  def __init__(self, nbits, world, rank, eng, *, exchange='alltoall', chunk_amps=1 << 22):
+    self.rank, self.world = int(rank), int(world)
     self.g = int(math.log2(self.world))
     assert 1 << self.g == self.world, 'number of ranks must be a power of two'
     self.nbits = int(nbits)
     self.nloc = self.nbits - self.g
     assert self.nloc >= 2, 'shard too small'
-    local_rank = int(os.environ.get('LOCAL_RANK', '0')) if local_rank is None else local_rank
-    self.bit_width = int(bit_width)
-    self.amp_bytes = 16 if self.bit_width == 128 else 8
-    self.cdtype = np.complex128 if self.bit_width == 128 else np.complex64
-    self._local_rank = local_rank
-    want_torch_p2p = os.environ.get('QCC_EXCHANGE') == 'torch'
-    factory = engine_factory or (lambda nloc: _hip_engine_factory(nloc, local_rank, fusion, self.bit_width, want_torch_p2p))
-    self.eng, self.buf = factory(self.nloc)
-    self._hip = hasattr(self.eng, 'lib')          # the real engine: knows its shard, builds states on the device
-    if self._hip:
-      self.eng.set_shard(self.nbits, self.rank)
-    # the real engine resolves shard-bit controls itself and must see every gate on every rank (ghosts, planner.h)
-    self._pass_all = self._hip and not want_torch_p2p
+    self.eng = eng
     # logical bit b (0 = least significant; qubit q is bit nbits-1-q) -> physical bit
     self.perm = list(range(self.nbits))
     self.chunk = min(int(chunk_amps), 1 << (self.nloc - 1))
@@ -124,72 +75,14 @@ class ShardedState:
     self.min_evict_bit = max(2, min(20, self.nloc - 3 * self.g))
     self._last_use = {}      # physical bit -> sequence number of its last use as a dense target
     self._seq = 0
-    self._staging = None
     self.exchanges = 0
     self.exchanged_bytes = 0
-    self.exchange_seconds = 0.0
     self.gates = 0
-    self.exchange_path = 'torch-p2p'
-    self._x0 = {}
     self._native_chunk = int(os.environ.get('QCC_EXCHANGE_CHUNK_AMPS', '0')) or self.chunk
-    if self.world > 1 or os.environ.get('QCC_EXCHANGE') == 'native':
-      self._init_native_exchange()
-    elif self._hip and self.buf is None:
-      self.exchange_path = 'none (one rank: nothing to exchange)'
-    if self._hip and self.buf is None and not self._native and self.world > 1:
-      raise RuntimeError(f'the engine-native exchange could not be set up ({self.exchange_path}); '
-                         'QCC_EXCHANGE=torch selects the torch.distributed double explicitly')
-    self.relayout = self._agree_on_relayout()
-
-  def _init_native_exchange(self):
-    """Engine-native transport when the engine is the HIP one (see the module docstring)."""
-    if not hasattr(self.eng, 'comm_init') or os.environ.get('QCC_EXCHANGE') == 'torch':
-      return
-    dist, torch = self.dist, self.torch
-    try:
-      if dist.get_backend() == 'gloo':
-        def round_fn(peers, send, recv):
-          ops = []
-          for p, s_, r_ in zip(peers, send, recv):
-            ops.append(dist.P2POp(dist.isend, torch.from_numpy(s_), p))
-            ops.append(dist.P2POp(dist.irecv, torch.from_numpy(r_), p))
-          for req in dist.batch_isend_irecv(ops):
-            req.wait()
-        self.eng.comm_init_custom(self.world, self.rank, round_fn)
-        self.exchange_path = 'host-staged'
-      else:
-        box = [self.eng.comm_unique_id() if self.rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        self.eng.comm_init(self.world, self.rank, box[0])
-        self.exchange_path = 'rccl'
-    except Exception as e:  # pylint: disable=broad-except
-      # every rank must take the same path: agree on success
-      self.exchange_path = f'torch-p2p (engine-native transport unavailable: {e})'
-    ok = torch.tensor([1 if self.exchange_path in ('rccl', 'host-staged') else 0], dtype=torch.int32,
-                      device=self._red_device())
-    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-    if int(ok.item()) == 0 and self.exchange_path in ('rccl', 'host-staged'):
-      self.eng.comm_destroy()
-      self.exchange_path = 'torch-p2p (another rank could not start the engine-native transport)'
 
   @property
-  def _native(self):
-    return self.exchange_path in ('rccl', 'host-staged')
-
-  def _agree_on_relayout(self):
-    """Relayout sweeps need a second buffer of the shard's size on EVERY rank (the ranks must hold the same
-    layout when they exchange): each rank tries, and one that cannot makes all of them give it back."""
-    if not self._hip or self.buf is not None or not hasattr(self.eng, 'set_relayout'):
-      return False
-    if self.world == 1:
-      return None                            # the engine decides at its first flush, like any single-GPU handle
-    mine = 1 if self.eng.set_relayout(True) else 0
-    t = self.torch.tensor([mine], dtype=self.torch.int32, device=self._red_device())
-    self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
-    if int(t.item()) == 0:
-      self.eng.set_relayout(False)
-      return False
-    return True
+  def amp_bytes(self):
+    return 16 if getattr(self, 'bit_width', 128) == 128 else 8
 
   # ------------------------------------------------------------------ helpers
   def _phys_mask(self, logical_mask):
@@ -211,53 +104,22 @@ class ShardedState:
         out |= 1 << b
     return out
 
-  def init_basis(self, index):
-    """|index> (logical); only the owning rank gets the 1."""
-    phys = self.logical_to_phys(int(index))
-    if self._hip:
-      self.eng.init_basis(phys)             # (this layer's physical bits are the engine's logical ones: it keeps its own map of
-      return                                #  where its relayout sweeps have moved the local bits)
-    self.eng.sync()
-    self.buf.zero_()
-    if self.buf.is_cuda:
-      self.torch.cuda.synchronize()
-    if (phys >> self.nloc) == self.rank:
-      self.buf[2 * (phys & ((1 << self.nloc) - 1))] = 1.0
-    if self.buf.is_cuda:
-      self.torch.cuda.synchronize()
-
   # ------------------------------------------------------------------ gates
   def apply_bits(self, ctl_mask, tgt_bit, gate):
-    """Gate on LOGICAL bit tgt_bit under logical control mask (all ranks call this)."""
+    """Gate on LOGICAL bit tgt_bit under logical control mask (all ranks call this).  Shard-bit controls and
+    diagonal gates on shard bits are resolved by the engine (it knows its shard: qh_set_shard), which must see
+    every gate on every rank (ghosts, planner.h)."""
     g4 = np.asarray(gate, dtype=np.complex128).reshape(4)
     self.gates += 1
     pt = self.perm[tgt_bit]
-    diag = _is_diag(g4)
+    diag = g4[1] == 0 and g4[2] == 0
     if pt >= self.nloc and not diag:
-      self._exchange(pt)                      # collective: before any rank-dependent skip
+      self._exchange(pt)                      # collective: before anything rank-dependent
       pt = self.perm[tgt_bit]
     if not diag:
       self._seq += 1
       self._last_use[pt] = self._seq
-    pm = self._phys_mask(ctl_mask)
-    if self._pass_all:
-      self.eng.apply_bits(pm, pt, g4)          # shard-bit controls / diagonal shard targets: resolved by the engine
-      return
-    hi = pm >> self.nloc
-    if (self.rank & hi) != hi:
-      return                                   # a control lives in the rank index and is 0 here
-    cm = pm & ((1 << self.nloc) - 1)
-    if pt >= self.nloc:                        # diagonal on a shard bit: rank-dependent factor
-      f = g4[3] if (self.rank >> (pt - self.nloc)) & 1 else g4[0]
-      if f == 1:
-        return
-      if cm:
-        c = (cm & -cm).bit_length() - 1
-        self.eng.apply_bits(cm & ~(1 << c), c, np.array([1, 0, 0, f], dtype=np.complex128))
-      else:
-        self.eng.apply_bits(0, 0, np.array([f, 0, 0, f], dtype=np.complex128))
-      return
-    self.eng.apply_bits(cm, pt, g4)
+    self.eng.apply_bits(self._phys_mask(ctl_mask), pt, g4)
 
   def apply1(self, gate, index):
     self.apply_bits(0, self.nbits - 1 - int(index), gate)
@@ -272,35 +134,24 @@ class ShardedState:
     """Replay (ops int32[G,2], gates float64[G,8]) in reference qubit numbers.
 
     Same routing as apply_bits, with the per-gate Python work reduced to a few
-    integer operations (the common case -- local target, at most one control --
-    goes straight to qh_apply_bits with a pointer into `gates8`)."""
+    integer operations (every gate goes straight to qh_apply_bits with a pointer into `gates8`)."""
     ops = np.ascontiguousarray(ops, dtype=np.int32)
     g8 = np.ascontiguousarray(gates8, dtype=np.float64)
-    n, nloc, rank = self.nbits, self.nloc, self.rank
+    n, nloc = self.nbits, self.nloc
     diag = ((g8[:, 2:6] == 0).all(axis=1)).tolist()
     tbits = (n - 1 - ops[:, 1]).tolist()
     cq = ops[:, 0].tolist()
     base = g8.ctypes.data
     raw = self.eng.apply_bits_raw
     perm = self.perm
-    gc = None
-    pass_all = self._pass_all
     for k in range(len(cq)):
       tb = tbits[k]
       pt = perm[tb]
-      if pt >= nloc:
-        if not diag[k]:
-          evict = self._evict_group(tbits, diag, k) if self.exchange_mode == 'alltoall' else None
-          self._exchange(pt, evict)
-          perm = self.perm
-          pt = perm[tb]
-        elif not pass_all:                     # diagonal on a shard bit: general path
-          if gc is None:
-            gc = g8.view(np.complex128).reshape(-1, 4)
-          cmask = 0 if cq[k] == NO_CTL else 1 << (n - 1 - cq[k])
-          self.apply_bits(cmask, tb, gc[k])
-          self.gates -= 1                      # apply_bits counted it; the total is added below
-          continue
+      if pt >= nloc and not diag[k]:
+        evict = self._evict_group(tbits, diag, k) if self.exchange_mode == 'alltoall' else None
+        self._exchange(pt, evict)
+        perm = self.perm
+        pt = perm[tb]
       if not diag[k]:
         self._seq += 1
         self._last_use[pt] = self._seq
@@ -312,83 +163,21 @@ class ShardedState:
           raise ValueError(f'control qubit {cq[k]} out of range')
         if c == tb:
           raise ValueError(f'control == target (qubit {cq[k]})')
-        pc = perm[c]
-        if pc >= nloc and not pass_all:
-          if not (rank >> (pc - nloc)) & 1:
-            continue
-          cm = 0
-        else:
-          cm = 1 << pc
+        cm = 1 << perm[c]
       raw(cm, pt, base + 64 * k)
     self.gates += len(cq)
 
   # ------------------------------------------------------------------ the exchange step
-  def _post_swap(self, pairs, parity):
-    """Start `send view to peer / receive peer's data` for every (peer, view).
-
-    Returns (requests, [(view, landing buffer)]).  NCCL/RCCL moves HBM views
-    directly into one of two staging halves; with the gloo backend and a
-    GPU-resident shard (used to test this layer with several processes on ONE GPU)
-    the chunks are staged through host memory."""
-    torch, dist = self.torch, self.dist
-    via_host = self.buf.is_cuda and dist.get_backend() == 'gloo'
-    ops, recv = [], []
-    half = self._staging.numel() // 2
-    for slot, (peer, view) in enumerate(pairs):
-      n = view.numel()
-      if via_host:
-        src = view.cpu()
-        dst = torch.empty_like(src)
-      else:
-        src = view
-        lo = parity * half + self._stage_stride * slot
-        dst = self._staging[lo: lo + n]
-      ops.append(dist.P2POp(dist.isend, src, peer))
-      ops.append(dist.P2POp(dist.irecv, dst, peer))
-      recv.append((view, dst))
-    return dist.batch_isend_irecv(ops), recv
-
-  @staticmethod
-  def _finish_swap(posted):
-    reqs, recv = posted
-    for req in reqs:
-      req.wait()
-    for view, dst in recv:
-      view.copy_(dst)
-
-  def _swap_all(self, chunk_lists):
-    """Run the chunk exchanges double-buffered: while chunk i is on the links, the
-    landing buffer of chunk i-1 is copied into place (the copy is ~15% of a chunk's
-    link time at xGMI rates, so this hides it)."""
-    prev = None
-    for i, pairs in enumerate(chunk_lists):
-      cur = self._post_swap(pairs, i & 1)
-      if prev is not None:
-        self._finish_swap(prev)
-      prev = cur
-    if prev is not None:
-      self._finish_swap(prev)
-
   def _exchange(self, shard_phys_bit, base=None):
-    import time
-    if self._native:
-      # asynchronous: queued sweeps, rounds and the following sweeps are ordered by HIP events
-      # inside the engine; its exchange timer is a HIP-event span (stats())
-      if self.exchange_mode == 'alltoall':
-        base = self.nloc - self.g if base is None else int(base)
-        self.eng.exchange_alltoall(base, self._native_chunk)
-        self._record_all(base)
-      else:
-        self.eng.exchange_pair(shard_phys_bit - self.nloc, self.nloc - 1, self._native_chunk)
-        self._record_pair(shard_phys_bit)
-      return
-    self.eng.sync()                      # local kernels first: the timer below is the exchange alone
-    t0 = time.perf_counter()
+    # asynchronous: queued sweeps, rounds and the following sweeps are ordered by HIP events
+    # inside the engine; its exchange timer is a HIP-event span (stats())
     if self.exchange_mode == 'alltoall':
-      self._exchange_all(base)
+      base = self.nloc - self.g if base is None else int(base)
+      self.eng.exchange_alltoall(base, self._native_chunk)
+      self._record_all(base)
     else:
-      self._exchange_pair(shard_phys_bit)
-    self.exchange_seconds += time.perf_counter() - t0
+      self.eng.exchange_pair(shard_phys_bit - self.nloc, self.nloc - 1, self._native_chunk)
+      self._record_pair(shard_phys_bit)
 
   def _evict_group(self, tbits, diag, k):
     """Which g consecutive local bits to hand to the shard index when gate k of a
@@ -424,43 +213,6 @@ class ShardedState:
       return max(never, key=lambda b: max(self._last_use.get(b + j, -1) for j in range(g)))
     return max(groups, key=lambda b: nxt[b])
 
-  def _exchange_all(self, base=None):
-    """Swap ALL g shard bits with g consecutive local bits [base, base+g) in one step
-    (default: the top g local bits).
-
-    The shard is P blocks selected by those g local bits; block j goes to rank j
-    and lands there as block `rank`; block `rank` stays.  Every rank talks to its
-    P-1 peers at once (one grouped send/recv per peer and chunk), so all xGMI
-    links of the GPU carry 1/P of the shard each -- instead of g successive
-    pairwise exchanges of half a shard over a single link.  In place: chunks go
-    through a (P-1) x chunk staging buffer.  With base below the top, a block is
-    2^(nloc-base-g) runs of 2^base contiguous amplitudes."""
-    torch = self.torch
-    P, g, r = self.world, self.g, self.rank
-    base = self.nloc - g if base is None else int(base)
-    assert 0 <= base <= self.nloc - g
-    run = 1 << base                                  # contiguous amplitudes per run
-    nruns = 1 << (self.nloc - base - g)
-    stride = run << g
-    chunk = min(self.chunk, run)
-    self.eng.sync()
-    need = 2 * (2 * chunk * (P - 1))                 # two halves: double buffering
-    if self._staging is None or self._staging.numel() < need:
-      self._staging = torch.empty(need, dtype=self.buf.dtype, device=self.buf.device)
-    self._stage_stride = 2 * chunk
-    peers = [j for j in range(P) if j != r]
-
-    def chunks():
-      for hi in range(nruns):
-        for off in range(0, run, chunk):
-          n = min(chunk, run - off)
-          yield [(j, self.buf[2 * (hi * stride + j * run + off): 2 * (hi * stride + j * run + off + n)])
-                 for j in peers]
-    self._swap_all(chunks())
-    if self.buf.is_cuda:
-      torch.cuda.synchronize()
-    self._record_all(base)
-
   def _record_all(self, base):
     g = self.g
     for k in range(g):                               # shard bit k <-> local bit base+k
@@ -478,24 +230,164 @@ class ShardedState:
     self.exchanges += 1
     self.exchanged_bytes += (1 << top) * self.amp_bytes
 
-  def _exchange_pair(self, shard_phys_bit):
-    """Swap the data of physical shard bit with the top local bit (pairwise, in place)."""
-    torch, dist = self.torch, self.dist
-    k = shard_phys_bit - self.nloc
-    top = self.nloc - 1
-    partner = self.rank ^ (1 << k)
-    mybit = (self.rank >> k) & 1
-    half = 1 << top                                   # amplitudes
-    start = (1 - mybit) * half                        # the half whose top bit != my shard bit
-    self.eng.sync()                                   # kernels done before RCCL touches the shard
-    if self._staging is None or self._staging.numel() < 4 * self.chunk:
-      self._staging = torch.empty(4 * self.chunk, dtype=self.buf.dtype, device=self.buf.device)
-    self._stage_stride = 2 * self.chunk
-    self._swap_all([(partner, self.buf[2 * (start + off): 2 * (start + min(off + self.chunk, half))])]
-                   for off in range(0, half, self.chunk))
-    if self.buf.is_cuda:
-      torch.cuda.synchronize()
-    self._record_pair(shard_phys_bit)                 # the two logical bits trade physical homes
+
+class DryShard(ShardRouter):
+  """ONE rank of a sharded run, planned and never executed: the routing above over a planner-only engine handle
+  (qh_create_dry + qh_set_shard + qh_comm_init_dry).  `geometries` collects how each exchange would be cut
+  (qh_xgeom: signature, slabs, rounds, chunk size, packed / direct, staging bytes, sweeps planned before it).  No
+  device, no torch, no process group: the pre-flight check of a multi-GPU configuration --
+  tests/test_exchange_geometry_cpu.py plans BASELINE config 5 (36 qubits on 8 GPUs) for all eight ranks this way
+  and compares what they would do."""
+
+  def __init__(self, nbits, world, rank, *, bit_width=128, relayout=True, **kw):
+    from qcc_amd import device, native
+    self.bit_width = int(bit_width)
+    nloc = int(nbits) - int(math.log2(world))
+    eng = device.DeviceState(nloc, bit_width, fusion=native.QH_FUSE_SWEEP, dry=True)
+    eng.set_shard(nbits, rank)
+    eng.comm_init_dry(world, rank)
+    super().__init__(nbits, world, rank, eng, **kw)
+    self.geometries = []
+
+  def _exchange(self, shard_phys_bit, base=None):
+    super()._exchange(shard_phys_bit, base)
+    geo = self.eng.exchange_geometry()
+    geo['bitmap_after'] = list(self.perm)
+    self.geometries.append(geo)
+
+  def flush(self):
+    self.eng.flush()
+
+  def stats(self):
+    s = self.eng.stats()
+    s.update(exchanges=self.exchanges, exchanged_bytes=self.exchanged_bytes)
+    return s
+
+  def close(self):
+    self.eng.close()
+
+
+def _hip_engine_factory(nloc, local_rank, fusion, bit_width=128):
+  """The engine of one rank on cuda:local_rank; it owns its shard."""
+  import torch
+  from qcc_amd import device
+  if not torch.cuda.is_available():
+    raise RuntimeError('torch sees no GPU.  If the engine library was loaded before torch was imported, two HIP '
+                       'runtimes are mapped (see qcc_amd.native._preload_torch_runtime): import torch first or '
+                       'launch through torchrun / set QCC_PRELOAD_TORCH=1')
+  torch.cuda.set_device(local_rank)
+  return device.DeviceState(nloc, bit_width, device=local_rank, fusion=fusion)
+
+
+class TransportError(RuntimeError):
+  """The engine-native exchange transport could not be set up on every rank (raised on EVERY rank)."""
+
+
+class ShardedState(ShardRouter):
+  """State (complex128, or complex64 with bit_width=64) sharded by its top log2(P) physical index bits."""
+
+  def __init__(self, nbits, fusion=1, local_rank=None, *, engine_factory=None, backend=None,
+               chunk_amps=1 << 22, exchange='alltoall', bit_width=128):
+    import torch
+    import torch.distributed as dist
+    self.torch, self.dist = torch, dist
+    if not dist.is_initialized():
+      # QCC_DIST_BACKEND=gloo: several ranks on ONE GPU (tests of this layer); RCCL refuses that
+      backend = backend or os.environ.get('QCC_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
+      os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+      if 'RANK' not in os.environ and 'WORLD_SIZE' not in os.environ:   # not under torchrun: a world of one
+        os.environ.update(RANK='0', WORLD_SIZE='1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+      kw = {}
+      if backend == 'nccl' and local_rank is not None:
+        torch.cuda.set_device(local_rank)
+        try:
+          kw['device_id'] = torch.device(f'cuda:{local_rank}')
+        except Exception:  # pylint: disable=broad-except
+          kw = {}
+      import datetime
+      # (a rank that never shows up must end the job, not hang it: bench.py turns the timeout into an error line)
+      kw['timeout'] = datetime.timedelta(seconds=int(os.environ.get('QCC_DIST_TIMEOUT_S', '900')))
+      dist.init_process_group(backend=backend, **kw)
+    rank, world = dist.get_rank(), dist.get_world_size()
+    g = int(math.log2(world))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0')) if local_rank is None else local_rank
+    self.bit_width = int(bit_width)
+    self.cdtype = np.complex128 if self.bit_width == 128 else np.complex64
+    self._local_rank = local_rank
+    nloc = int(nbits) - g
+    factory = engine_factory or (lambda nl: _hip_engine_factory(nl, local_rank, fusion, self.bit_width))
+    eng = factory(nloc)
+    eng.set_shard(int(nbits), rank)     # the engine resolves shard-bit controls itself and sees every gate on every rank
+    super().__init__(nbits, world, rank, eng, exchange=exchange, chunk_amps=chunk_amps)
+    self.exchange_seconds = 0.0
+    self.exchange_path = 'none (one rank: nothing to exchange)'
+    self._x0 = {}
+    if self.world > 1 or os.environ.get('QCC_EXCHANGE') == 'native':
+      self._init_transport()
+    self.relayout = self._agree_on_relayout()
+
+  def _init_transport(self):
+    """The engine's exchange transport: RCCL under the nccl backend, host-staged rounds carried by gloo otherwise.
+    Every rank must end up with the same transport: the ranks agree on success, and a failure anywhere raises
+    TransportError EVERYWHERE -- a mis-set-up communicator is an error message, never a different data path."""
+    dist, torch = self.dist, self.torch
+    err = None
+    try:
+      if dist.get_backend() == 'gloo':
+        def round_fn(peers, send, recv):
+          ops = []
+          for p, s_, r_ in zip(peers, send, recv):
+            ops.append(dist.P2POp(dist.isend, torch.from_numpy(s_), p))
+            ops.append(dist.P2POp(dist.irecv, torch.from_numpy(r_), p))
+          for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        self.eng.comm_init_custom(self.world, self.rank, round_fn)
+        self.exchange_path = 'host-staged'
+      else:
+        box = [self.eng.comm_unique_id() if self.rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        self.eng.comm_init(self.world, self.rank, box[0])
+        self.exchange_path = 'rccl'
+    except Exception as e:  # pylint: disable=broad-except
+      err = f'{type(e).__name__}: {e}'
+      self.exchange_path = f'failed on rank {self.rank} ({err})'
+    ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=self._red_device())
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) == 0:
+      if err is None:
+        try:
+          self.eng.comm_destroy()
+        except Exception:  # pylint: disable=broad-except
+          pass
+        self.exchange_path = 'failed on another rank'
+      raise TransportError(f'the engine-native exchange transport could not be set up on every rank: rank {self.rank}: '
+                           f'{err or "ok here, another rank failed"}')
+
+  @property
+  def _native(self):
+    return self.exchange_path in ('rccl', 'host-staged')
+
+  def _agree_on_relayout(self):
+    """Relayout sweeps need a second buffer of the shard's size on EVERY rank (the ranks must hold the same
+    layout when they exchange): each rank tries, and one that cannot makes all of them give it back."""
+    if not hasattr(self.eng, 'set_relayout'):
+      return False
+    if self.world == 1:
+      return None                            # the engine decides at its first flush, like any single-GPU handle
+    mine = 1 if self.eng.set_relayout(True) else 0
+    t = self.torch.tensor([mine], dtype=self.torch.int32, device=self._red_device())
+    self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+    if int(t.item()) == 0:
+      self.eng.set_relayout(False)
+      return False
+    return True
+
+  def init_basis(self, index):
+    """|index> (logical); only the owning rank gets the 1."""
+    # (this layer's physical bits are the engine's logical ones: it keeps its own map of where its relayout sweeps
+    #  have moved the local bits)
+    self.eng.init_basis(self.logical_to_phys(int(index)))
 
   # ------------------------------------------------------------------ readers
   def flush(self):
@@ -508,7 +400,7 @@ class ShardedState:
     """Device for the tiny reduction tensors: the shard's device under RCCL, host under gloo."""
     if self.dist.get_backend() == 'gloo':
       return 'cpu'
-    return self.buf.device if self.buf is not None else f'cuda:{self._local_rank}'
+    return f'cuda:{self._local_rank}'
 
   def norm2_global(self):
     if self.exchange_path == 'rccl':          # 8 bytes over the engine's own communicator
@@ -543,37 +435,19 @@ class ShardedState:
     phys = self.logical_to_phys(int(logical_index))
     if (phys >> self.nloc) != self.rank:
       return None
-    local = phys & ((1 << self.nloc) - 1)
-    knows_shard = getattr(self.eng, 'nbits_global', self.nloc) > self.nloc   # (ShardedDevice sets it)
-    return self.eng.amplitude(((self.rank << self.nloc) | local) if knows_shard else local)
+    return self.eng.amplitude(phys)             # (the engine knows its shard: global index)
 
   def gather_logical(self):
     """Whole state in LOGICAL order on every rank (tests / small n only)."""
     torch = self.torch
     self.eng.sync()
-    if self.buf is None:                    # the engine owns the shard: download it (canonical order of its local bits)
-      mine = torch.from_numpy(self.eng.download().view(np.float64 if self.bit_width == 128 else np.float32))
-      if self.dist.get_backend() != 'gloo':
-        mine = mine.to(self._red_device())
-      parts = [torch.zeros_like(mine) for _ in range(self.world)]
-      self.dist.all_gather(parts, mine)
-      phys = np.concatenate([p_.cpu().numpy().view(self.cdtype) for p_ in parts])
-      idx = np.arange(1 << self.nbits, dtype=np.uint64)
-      pidx = np.zeros_like(idx)
-      for b in range(self.nbits):
-        pidx |= ((idx >> np.uint64(b)) & np.uint64(1)) << np.uint64(self.perm[b])
-      return phys[pidx]
-    if self.buf.is_cuda:
-      torch.cuda.synchronize()
-    mine = self.buf.detach().to('cpu') if self.buf.is_cuda else self.buf
+    # the engine owns the shard: download it (canonical order of its local bits)
+    mine = torch.from_numpy(self.eng.download().view(np.float64 if self.bit_width == 128 else np.float32))
+    if self.dist.get_backend() != 'gloo':
+      mine = mine.to(self._red_device())
     parts = [torch.zeros_like(mine) for _ in range(self.world)]
-    if self.buf.is_cuda and self.dist.get_backend() != 'gloo':
-      cu = [torch.zeros_like(self.buf) for _ in range(self.world)]
-      self.dist.all_gather(cu, self.buf)
-      parts = [c.cpu() for c in cu]
-    else:
-      self.dist.all_gather(parts, mine)
-    phys = np.concatenate([p.numpy().view(self.cdtype) for p in parts])
+    self.dist.all_gather(parts, mine)
+    phys = np.concatenate([p_.cpu().numpy().view(self.cdtype) for p_ in parts])
     idx = np.arange(1 << self.nbits, dtype=np.uint64)
     pidx = np.zeros_like(idx)
     for b in range(self.nbits):
@@ -605,6 +479,8 @@ class ShardedState:
       s['exchange_rounds'] = x['rounds'] - self._x0.get('rounds', 0)
       s['exchange_slabs'] = x['slabs'] - self._x0.get('slabs', 0)
       s['sweeps_overlapped_with_exchange'] = x['sweeps_overlapped'] - self._x0.get('sweeps_overlapped', 0)
+      if hasattr(self.eng, 'exchange_geometry') and self.exchanges:
+        s['exchange_geometry'] = self.eng.exchange_geometry()
     return s
 
   def reset_stats(self):
@@ -617,11 +493,6 @@ class ShardedState:
   def close(self):
     self.eng.sync()
     self.eng.close()
-    if self.buf is not None and getattr(self.buf, 'is_cuda', False):
-      # hand the shard (up to 128 GiB) back to the driver: torch's caching allocator would keep it,
-      # and the engine's own hipMalloc calls in this process do not see torch's cache
-      self.buf = self._staging = None
-      self.torch.cuda.empty_cache()
 
 
 class ShardedDevice:
@@ -637,14 +508,8 @@ class ShardedDevice:
     self.st = ShardedState(nbits, fusion=fusion, bit_width=bit_width, **kw)
     self.nbits, self.bit_width = int(nbits), int(bit_width)
     self.dtype = self.st.cdtype
-    st = self.st
-    self._hip = st._hip                       # the real engine (device readers, init_product on the shard)
 
   # -- helpers ---------------------------------------------------------------------
-  def _local_view(self):
-    """complex view [2^nloc] of the shard as a torch tensor (CPU stand-in engines only)."""
-    return self.st.torch.view_as_complex(self.st.buf.view(-1, 2))
-
   def _all_sum(self, values):
     st = self.st
     if st.exchange_path == 'rccl':           # the engine's communicator (one communicator on the data path)
@@ -664,33 +529,15 @@ class ShardedDevice:
 
   def init_product(self, factors):
     """Each rank builds ITS slice of f_0 (x) f_1 (x) ... in place (qh_init_product knows the shard)."""
-    st = self.st
     self._reset_map()
-    if self._hip:
-      st.eng.init_product(factors)
-      return
-    idx = (np.uint64(st.rank) << np.uint64(st.nloc)) | np.arange(1 << st.nloc, dtype=np.uint64)
-    out = np.ones(idx.shape, dtype=np.complex128)
-    shift = st.nbits
-    for n, x in factors:
-      shift -= n
-      v = ((idx >> np.uint64(shift)) & np.uint64((1 << n) - 1)).astype(np.int64)
-      if isinstance(x, (int, np.integer)):
-        out *= (v == int(x))
-      else:
-        out *= np.asarray(x, dtype=np.complex128).reshape(-1)[v]
-    st.buf.copy_(st.torch.from_numpy(out.view(np.float64)))
+    self.st.eng.init_product(factors)
 
   def upload(self, host, offset=0):
     assert offset == 0
     st = self.st
     self._reset_map()
     a = np.ascontiguousarray(host, dtype=self.dtype).reshape(-1)
-    part = a[st.rank << st.nloc: (st.rank + 1) << st.nloc]
-    if self._hip:
-      st.eng.upload(part)
-    else:
-      st.buf.copy_(st.torch.from_numpy(part.view(np.float64 if self.bit_width == 128 else np.float32).copy()))
+    st.eng.upload(a[st.rank << st.nloc: (st.rank + 1) << st.nloc])
 
   def download(self, offset=0, count=None, out=None):
     full = self.st.gather_logical()
@@ -731,12 +578,8 @@ class ShardedDevice:
     value = 1 if value else 0
     if pb >= st.nloc:
       p = st.eng.norm2() if ((st.rank >> (pb - st.nloc)) & 1) == value else 0.0
-    elif self._hip:
-      p = st.eng.prob_bit(pb, value)
     else:
-      st.eng.sync()
-      v = self._local_view().view(-1, 2, 1 << pb)[:, value, :]
-      p = float((v.real ** 2 + v.imag ** 2).sum())
+      p = st.eng.prob_bit(pb, value)
     return self._all_sum([p])[0]
 
   def project_bit(self, logical_bit, value):
@@ -745,20 +588,12 @@ class ShardedDevice:
     value = 1 if value else 0
     if pb >= st.nloc:
       if ((st.rank >> (pb - st.nloc)) & 1) != value:
-        self.scale(0.0, _local=True)
-    elif self._hip:
+        st.eng.scale(0.0)
+    else:
       st.eng.project_bit(pb, value)
-    else:
-      st.eng.sync()
-      self._local_view().view(-1, 2, 1 << pb)[:, 1 - value, :] = 0
 
-  def scale(self, z, _local=False):
-    st = self.st
-    if self._hip:
-      st.eng.scale(z)
-    else:
-      st.eng.sync()
-      self._local_view().mul_(complex(z))
+  def scale(self, z):
+    self.st.eng.scale(z)
 
   def stats(self):
     return self.st.stats()

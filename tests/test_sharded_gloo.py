@@ -52,8 +52,7 @@ def _worker(rank, world, port, n, seed, out_dir, mode='alltoall'):
   from tests import fake_device
 
   def factory(nloc):
-    e = fake_device.NumpyShardEngine(nloc)
-    return e, e.buf
+    return fake_device.NumpyShardEngine(nloc)
   st = sharded.ShardedState(n, engine_factory=factory, chunk_amps=8, exchange=mode)   # tiny chunks: many rounds
   ops, g8 = _stream(n, seed)
   x = 0b1011010 & ((1 << n) - 1)
@@ -119,8 +118,7 @@ def _qft_repeat(rank, world, port, n, reps, out_dir):
   from tests import fake_device, oracle_lib
 
   def factory(nloc):
-    e = fake_device.NumpyShardEngine(nloc)
-    return e, e.buf
+    return fake_device.NumpyShardEngine(nloc)
   st = sharded.ShardedState(n, engine_factory=factory, chunk_amps=16)
   st.min_evict_bit = 2
   st.init_basis(0b1100101)
@@ -151,8 +149,7 @@ def _qft_only(rank, world, port, n, out_dir):
   from tests import fake_device
 
   def factory(nloc):
-    e = fake_device.NumpyShardEngine(nloc)
-    return e, e.buf
+    return fake_device.NumpyShardEngine(nloc)
   st = sharded.ShardedState(n, engine_factory=factory)
   st.init_basis(0b0110101)
   ops, g8 = workloads.qft_stream(range(n)).arrays()
@@ -162,6 +159,40 @@ def _qft_only(rank, world, port, n, out_dir):
     np.savez(os.path.join(out_dir, 'qft.npz'), psi=full, exchanges=st.exchanges)
   dist.barrier()
   dist.destroy_process_group()
+
+
+def _broken_transport_worker(rank, world, port, out_dir):
+  os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                    LOCAL_RANK=str(rank))
+  import torch.distributed as dist
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  from qcc_amd import sharded
+  from tests import fake_device
+
+  class Broken(fake_device.NumpyShardEngine):
+    def comm_init_custom(self, nranks, rank_, round_fn):
+      if rank_ == 1:
+        raise RuntimeError('no transport on this rank')
+      super().comm_init_custom(nranks, rank_, round_fn)
+  try:
+    sharded.ShardedState(8, engine_factory=Broken)
+    outcome = 'constructed'
+  except sharded.TransportError as e:
+    outcome = f'TransportError: {e}'
+  with open(os.path.join(out_dir, f'outcome{rank}.txt'), 'w') as f:
+    f.write(outcome)
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def test_a_transport_that_fails_on_one_rank_is_an_error_on_every_rank(tmp_path):
+  """a communicator that cannot be set up must be an error everywhere -- never a silent agreement on some
+  other data path.  Rank 1's engine refuses; ranks 0..3 all raise TransportError, each saying where it failed."""
+  world = 4
+  mp.spawn(_broken_transport_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+  texts = [open(tmp_path / f'outcome{r}.txt').read() for r in range(world)]
+  assert all(t.startswith('TransportError') for t in texts), texts
+  assert 'no transport on this rank' in texts[1] and 'another rank failed' in texts[0]
 
 
 # ---- circuit.qc() on a sharded register (north_star: "every algorithm runs unmodified") ----------
@@ -199,8 +230,7 @@ def _qc_worker(rank, world, port, golden, out_dir):
   from tests import fake_device
 
   def factory(nloc):
-    e = fake_device.NumpyShardEngine(nloc)
-    return e, e.buf
+    return fake_device.NumpyShardEngine(nloc)
   made = []
 
   def device_factory(nbits, bw):
