@@ -590,8 +590,6 @@ class Planner {
   int lane_valu_ = env_int("QH_LANE_VALU", 1);          // 0 never, 1 by cost model (choose_lane_paths), 2 always (tests)
   bool defer_diag_ = env_flag("QH_DEFER_DIAG", true);   // see build_sweep
   bool lookahead_ = env_flag("QH_RELAYOUT_AHEAD", true); // see finish_relayout
-  bool relayout_contig_ = env_flag("QH_RELAYOUT_CONTIG", false);   // see want_relayout
-  bool lane3_least_ = env_flag("QH_LANE3_LEAST", false);           // see build_sweep (measured slower: off)
   bool reorder_ = env_flag("QH_REORDER", true);                    // see reorder_for_fewer_swaps
   bool lswap_early_ = env_flag("QH_LSWAP_EARLY", true);            // lane <-> register exchange before the phases of its gate (emit_ops_with)
   std::vector<uint64_t> alg_override_;
@@ -1042,21 +1040,6 @@ class Planner {
         lanemask = always | mask_of(lanehi);
       }
     }
-    // Of the three movable lane bits of a complex128 tile, lane bit 3 is the expensive seat: its butterflies fetch the
-    // partner by DPP (192 VALU instructions each, and their phases multiply all 32 slots), while lane bits 4 / 5 trade
-    // places with a register bit once (72) and run their gates there.  In a split-lane tile any index bit may take any
-    // lane role: the bit with the fewest dense gates takes lane bit 3.  MEASURED SLOWER (supremacy-30 32.9 -> 34.1 ms:
-    // saves four DPP butterflies per circuit but, where index bit 3 was a lane bit, breaks the 256-byte runs of lanes
-    // 0..15 into 128-byte ones), so it is off; kept for the record (QH_LANE3_LEAST=1).
-    if (lane3_least_ && lane_low_ == 3 && lanehi.size() == 3 &&
-        !(lanehi[0] == 3 && lanehi[1] == 4 && lanehi[2] == 5)) {
-      std::vector<int> cnt(64, 0);
-      for (const GateRec *r : taken)
-        if (!plan_diag(*r) && r->tgt >= 0) cnt[r->tgt]++;
-      size_t best = 0;
-      for (size_t i = 1; i < lanehi.size(); ++i) if (cnt[lanehi[i]] < cnt[lanehi[best]]) best = i;
-      if (best != 0) std::rotate(lanehi.begin(), lanehi.begin() + (long)best, lanehi.begin() + (long)best + 1);
-    }
     // drop register bits that ended up unused (a later candidate made them moot)
     {
       uint64_t used = 0;
@@ -1182,28 +1165,11 @@ class Planner {
     }
     const double floor_cycles = env_int("QH_LDS_FLOOR", 2500);   // (read at every flush, like the other planner switches)
     LaneChoice ch;
-    // QH_LANE_LDS_BUDGET (cycles of the LDS pipe per tile): instead of all-or-nothing, move lane butterflies to the VALU
-    // only until the LDS pipe fits the budget, cheapest VALU alternative first -- lane bits 4 / 5 (v_permlane swap: +72
-    // VALU instructions), then the one-move DPP bits 0, 1, 3 (+128), last lane bit 2 (+256).  The sweeps of a layered
-    // circuit are bound by VALU issue, not by latency: every butterfly left on the (otherwise idle) LDS pipe is 128-256
-    // VALU instructions less per tile.
-    const int budget = env_int("QH_LANE_LDS_BUDGET", -1);
-    if (budget >= 0) {
-      int n45 = 0, n013 = 0, n2 = 0;
-      for (const SweepOp &o : sp.ops) {
-        if (o.kind != OP_DENSE_LANE || !(o.flags & (OPF_BFLY | OPF_REAL))) continue;
-        if (o.tb >= 4) n45 += (o.flags & OPF_BFLY) ? 1 : 0;
-        else if (one_step_dpp(o.tb)) n013++;
-        else n2++;
-      }
-      double over = lds - budget;
-      auto move = [&](int avail) { int k = 0; while (k < avail && over > 0) { ++k; over -= kLds; } return k; };
-      const int m45 = move(n45), m013 = move(n013), m2 = move(n2);
-      ch.lswap = m45;
-      ch.dpp01 = ch.real01 = m013;
-      ch.dpp23 = ch.real23 = m2;
-      return ch;
-    }
+    // (Round 4 tried the middle ground -- leave butterflies on the otherwise idle LDS pipe up to a budget of pipe cycles
+    // per tile, cheapest VALU alternative moved first -- on the premise that op-heavy sweeps are bound by VALU issue:
+    // every butterfly left on ds_bpermute made every workload slower, supremacy-30 33.5 -> 33.6 / 34.0 / 34.4 / 40.8 ms
+    // for 1600 / 2500 / 3500 / unlimited cycles, QFT-30 16.5 -> 17.2-17.6: profiles/r04/lane_lds_budget_ab.txt.  The
+    // dependent latency of 128 shuffles behind eleven other waves is what costs, not the pipe's throughput.)
     if (lds > floor_cycles) ch.dpp01 = ch.dpp23 = ch.lswap = ch.real01 = ch.real23 = 1 << 20;
     return ch;
   }
@@ -1596,7 +1562,6 @@ class Planner {
   // may as well leave its tile bits on the low positions -- where they stay for the next flush.
   bool want_relayout(const SweepPlan &sp, bool has_swaps = false) const {
     if (!relayout_ || sp.fixed_ones) return false;      // (a sweep that skips amplitudes cannot move the rest)
-    if (has_swaps && relayout_contig_) return true;     // a contiguous tile with layout exchanges to undo: store them as they are
     const int low = sp.lane_low;
     for (int k = 0; k < sp.nlanehi(); ++k) if (sp.lanehi[k] != low + k) return true;
     for (int k = 0; k < sp.rb; ++k) if (sp.regpos[k] != kLaneBits + k) return true;

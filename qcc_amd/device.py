@@ -75,7 +75,13 @@ class DeviceState:
     elif host_mapped:
       native.check(self.lib.qh_create_host_mapped(self.nbits, self.bit_width, device, ctypes.byref(h)))
     elif device_ptr is None:
-      native.check(self.lib.qh_create(self.nbits, self.bit_width, device, ctypes.byref(h)))
+      rc = self.lib.qh_create(self.nbits, self.bit_width, device, ctypes.byref(h))
+      if rc == native.QH_ERR_NOMEM:
+        # device states parked by finished circuits (qcc_amd.lib.backend's pool) may be in the way: free them, try again
+        from qcc_amd.lib import backend  # pylint: disable=import-outside-toplevel
+        backend.drop_device_pool()
+        rc = self.lib.qh_create(self.nbits, self.bit_width, device, ctypes.byref(h))
+      native.check(rc)
     else:
       native.check(self.lib.qh_attach(self.nbits, self.bit_width, device,
                                       ctypes.c_void_p(device_ptr),

@@ -95,8 +95,68 @@ def set_host_mapped_factory(factory):
     _host_mapped_factory = factory
 
 
+# ---- device-state pool ------------------------------------------------------------------------------------------
+# A script that builds one circuit after another (the reference's algorithms do: src/lib/circuit.py:71-101 creates a
+# qc per experiment) paid for two fresh 16-GiB buffers per 30-qubit circuit: allocation + first touch ~ 3.8 s cold,
+# 12-17 ms warm (`single_shot_ms`).  Released states of the default factory are kept here, keyed by
+# (qubits, width), and handed to the next circuit of the same shape -- with their second buffer, op buffers and cached
+# plans.  Bounded: at most QCC_POOL_STATES handles (default 2) of at most QCC_POOL_MAX_QUBITS qubits (default 31: a
+# 34-qubit state is never parked); drop_device_pool() frees everything (also done when an allocation fails).
+_pool = {}
+_pool_order = []
+
+
+def _pool_limits():
+    return int(os.environ.get('QCC_POOL_STATES', '2')), int(os.environ.get('QCC_POOL_MAX_QUBITS', '31'))
+
+
+def drop_device_pool():
+    for dev in _pool_order:
+        try:
+            dev.close()
+        except Exception:  # pylint: disable=broad-except
+            pass
+    _pool.clear()
+    del _pool_order[:]
+
+
+def release_device_state(dev):
+    """Called by circuit.qc when it is done with a device state: park it for the next circuit, or close it."""
+    keep, max_bits = _pool_limits()
+    poolable = (_device_factory is None and keep > 0 and type(dev).__name__ == 'DeviceState' and dev.nbits <= max_bits
+                and getattr(dev, 'h', None) and int(os.environ.get('WORLD_SIZE', '1')) == 1)
+    if not poolable:
+        dev.close()
+        return
+    try:
+        native.check(dev.lib.qh_discard_pending(dev.h))
+        dev.reset_stats()
+    except Exception:  # pylint: disable=broad-except
+        dev.close()
+        return
+    _pool.setdefault((dev.nbits, dev.bit_width), []).append(dev)
+    _pool_order.append(dev)
+    while len(_pool_order) > keep:
+        old = _pool_order.pop(0)
+        _pool[(old.nbits, old.bit_width)].remove(old)
+        old.close()
+
+
 def make_device_state(nbits, bit_width):
-    return (_device_factory or _default_device_factory)(nbits, bit_width)
+    if _device_factory is not None:
+        return _device_factory(nbits, bit_width)
+    parked = _pool.get((nbits, bit_width))
+    if parked:
+        dev = parked.pop()
+        _pool_order.remove(dev)
+        return dev            # (its contents are whatever the last circuit left: the caller initialises the state)
+    try:
+        return _default_device_factory(nbits, bit_width)
+    except native.QhError as e:
+        if e.code != native.QH_ERR_NOMEM or not _pool_order:
+            raise
+        drop_device_pool()    # the parked buffers were in the way
+        return _default_device_factory(nbits, bit_width)
 
 
 def set_device_factory(factory):

@@ -48,7 +48,10 @@ except Exception:  # pylint: disable=broad-except
     _flags = None
 
 _SNAPSHOT_LIMIT_BITS = 31  # above this a full host snapshot is refused (>= 32 GiB)
-_MEASURE_SNAPSHOT_BITS = 26  # measure_bit returns the real State up to here (1 GiB), a lazy handle above
+_MEASURE_SNAPSHOT_BITS = 20  # measure_bit returns the real State up to here (16 MiB per call), a lazy handle above: loops of
+                             # repeated measurements at 22-26 qubits would otherwise download up to 1 GiB per iteration
+_QUEUE_FLUSH_GATES = 4096    # eager gates queued on the host side are handed to the engine in batches of this size, so the GPU starts
+                             # working while a long circuit is still being written down
 _ALIAS_LIMIT_BITS = 26     # alias_psi: registers up to this size live in host-mapped memory
 _NO_CTL = -(2 ** 31)       # "no control" in a gate stream (include/qcc_hip.h QH_NO_CTL)
 
@@ -197,9 +200,13 @@ class qc:
         """Hand the gates queued on the host side to the engine, in order."""
         if not self._q_ops:
             return
+        dev = self._device_ready()        # (may raise -- no memory, width change above the snapshot limit: the queue is kept)
         ops_, gs = self._q_ops, self._q_gates
         self._q_ops, self._q_gates = [], []
-        dev = self._device_ready()
+        # from here on the engine owns the gates: whatever happens, neither the product description nor a host snapshot
+        # describes the state any more
+        self._product_flag = False
+        self._host_ok = False
         if hasattr(dev, 'run_stream'):
             dev.run_stream(np.array(ops_, dtype=np.int32).reshape(-1, 2),
                            np.array(gs, dtype=np.complex128).reshape(-1, 4).view(np.float64).reshape(-1, 8))
@@ -230,7 +237,7 @@ class qc:
                                      f'resident at width {self._dev.bit_width}')
                 self._host, self._host_ok = state.State(self._dev.download()), True
             if not self._alias:
-                self._dev.close()     # (alias mode: State views handed out keep the mapped memory alive)
+                backend.release_device_state(self._dev)     # (alias mode: State views handed out keep the mapped memory alive)
             self._dev, self._dev_ok = None, False
         if self._dev is None:
             if self._alias and self._nbits <= _ALIAS_LIMIT_BITS:
@@ -414,6 +421,8 @@ class qc:
                         raise ValueError(f'apply1: qubit {idx} out of range for {self._nbits} qubits')
                     self._q_ops.append((_NO_CTL, int(idx)))
                     self._q_gates.append(np.array(gate, dtype=np.complex128).reshape(4))
+                    if len(self._q_ops) >= _QUEUE_FLUSH_GATES:
+                        self._drain()
                     continue
                 self._gate_done()
 
@@ -437,6 +446,8 @@ class qc:
                     raise ValueError(f'applyc: control == target (qubit {idx})')
                 self._q_ops.append((int(ctl_qubit), int(idx)))
                 self._q_gates.append(np.array(gate, dtype=np.complex128).reshape(4))
+                if len(self._q_ops) >= _QUEUE_FLUSH_GATES:
+                    self._drain()
             if self._aliased():
                 self._gate_done()
         self.x(ctl_qubit, by_0)
@@ -695,8 +706,16 @@ class qc:
             self._dev.sync()
 
     def close(self):
+        """Give the device state back (to the per-process pool of qcc_amd.lib.backend: the next circuit of the same
+        shape reuses its buffers instead of allocating 2 x 16 GiB again).  Also runs when the circuit is collected."""
         self._q_ops, self._q_gates = [], []
         if self._dev is not None:
             if not self._alias:
-                self._dev.close()
+                backend.release_device_state(self._dev)
             self._dev, self._dev_ok = None, False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # pylint: disable=broad-except
+            pass

@@ -244,3 +244,45 @@ def test_alias_psi_contract_on_host_mapped_memory(oracle):
   oracle.apply1(want, np.array([1, 1, 1, -1]) / np.sqrt(2), 20, 0)
   oracle.run_stream(want, 20, ops_, g8)
   assert np.max(np.abs(p - want)) < 1e-12
+
+
+def test_device_states_are_reused_across_circuits():
+  """qcc_amd.lib.backend's pool (reference call site src/lib/circuit.py:71-101: one qc per experiment):
+  a circuit that is closed or collected parks its device state; the next circuit of the same shape gets that handle --
+  buffers, second buffer and cached plans included -- and starts from ITS OWN initial state, not from what was left."""
+  backend.drop_device_pool()
+  n = 24
+  qc1 = circuit.qc('first')
+  r = qc1.reg(n, 5)
+  qc1.qft(r)
+  qc1.maxprob()
+  h1 = qc1._dev.h.value
+  del qc1                                          # collected -> parked
+  import gc
+  gc.collect()
+  assert sum(len(v) for v in backend._pool.values()) == 1
+  qc2 = circuit.qc('second')
+  r = qc2.reg(n, 0b1011)
+  qc2.h(r[n - 1])
+  bits, p = qc2.maxprob()
+  assert qc2._dev.h.value == h1 and not backend._pool_order      # the same handle, taken out of the pool
+  assert abs(p - 0.5) < 1e-12 and abs(qc2.norm2() - 1) < 1e-12
+  assert abs(abs(qc2.ampl(*[int(b) for b in format(0b1011, f'0{n}b')])) ** 2 - 0.5) < 1e-12
+  assert abs(abs(qc2.ampl(*[int(b) for b in format(0b1010, f'0{n}b')])) ** 2 - 0.5) < 1e-12
+  qc3 = circuit.qc('other shape')                  # another shape: its own handle
+  qc3.reg(20, 1)
+  qc3.h(0)
+  qc3.maxprob()
+  assert qc3._dev.h.value != h1
+  qc2.close(); qc3.close()
+  assert len(backend._pool_order) == 2
+  big = circuit.qc('too big to park')
+  big.reg(28, 0); big.h(0); big.maxprob()
+  os.environ['QCC_POOL_MAX_QUBITS'] = '27'
+  try:
+    big.close()
+    assert len(backend._pool_order) == 2 and all(d.nbits != 28 for d in backend._pool_order)
+  finally:
+    del os.environ['QCC_POOL_MAX_QUBITS']
+  backend.drop_device_pool()
+  assert not backend._pool_order

@@ -570,3 +570,46 @@ def test_qft_of_random_states_small_tiles_vs_oracle(oracle, monkeypatch, bw, lan
     tol = 1e-12 if bw == 128 else 2e-5
     assert np.max(np.abs(got - want)) <= tol, (n, bw)
     assert np.max(np.abs(back - psi0)) <= 2 * tol, (n, bw)
+
+
+@pytest.mark.parametrize('bw', [128, 64])
+def test_per_gate_kernel_shapes_every_target_at_22_qubits(oracle, bw):
+  """Round 4: the per-gate kernels pick their launch shape by target bit (kernels_gate.hip.h: k_pair_line for targets
+  inside the 128-byte line -- partner by DPP moves --, k_pair_tile / k_diag_tile wave tiles, U = 16 tiles for bits
+  20..25; engine.hip launch_pair / launch_diag).  Every target of a 22-qubit state, uncontrolled and under controls
+  on low, middle and high bits (inserted control bits below and above the target, the lowpred predicate on bits 0-1),
+  dense / real / anti-diagonal / diagonal gates, both widths -- unfused, against the oracle."""
+  n = 22
+  rng = np.random.default_rng(2200 + bw)
+  dtype = np.complex128 if bw == 128 else np.complex64
+  tol = TOL if bw == 128 else 2e-6
+  psi0 = _rand_state(rng, n, dtype)
+  dense = [_rand_unitary(rng), gates.hadamard(), gates.pauli_x(), gates.pauli_y(), gates.ry(0.7)]
+  diag = [gates.u1(0.37), gates.pauli_z(), gates.rz(0.9), gates.tgate()]
+  with device.DeviceState(n, bw, fusion=native.QH_FUSE_OFF) as st:
+    def check(apply_dev, apply_ref, what):
+      want = psi0.astype(np.complex128)
+      apply_ref(want)
+      st.upload(psi0)
+      apply_dev()
+      err = float(np.max(np.abs(st.download().astype(np.complex128) - want)))
+      assert err <= tol, (bw, what, err)
+    for q in range(n):                       # reference qubit q = index bit n-1-q
+      g = dense[q % len(dense)]
+      check(lambda: st.apply1(g, q), lambda w: oracle.apply1(w, g, n, q), ('apply1', q))
+      d = diag[q % len(diag)]
+      check(lambda: st.apply1(d, q), lambda w: oracle.apply1(w, d, n, q), ('apply1-diag', q))
+      for c in {(q + 1) % n, (q + 11) % n, n - 1, n - 2, n - 3, 0} - {q}:
+        check(lambda: st.applyc(g, c, q), lambda w: oracle.applyc(w, g, n, c, q), ('applyc', c, q))
+        check(lambda: st.applyc(d, c, q), lambda w: oracle.applyc(w, d, n, c, q), ('applyc-diag', c, q))
+    # several controls at once through qh_apply_bits (controls on index bits 0, 1 -> lane predicate; 2.. -> inserted)
+    idx = np.arange(1 << n, dtype=np.uint64)
+    for tgt_bit, cbits in ((0, (1, 2, 9)), (1, (0, 21)), (2, (0, 1, 3)), (5, (0, 2, 20)), (21, (0, 1, 2)), (20, (3, 21)), (12, (1, 13, 19))):
+      g = dense[tgt_bit % len(dense)]
+      cm = sum(1 << b for b in cbits)
+      def ref(w, g=g, cm=cm, tgt_bit=tgt_bit):
+        tmp = w.copy()
+        oracle.apply1(tmp, g, n, n - 1 - tgt_bit)
+        sel = (idx & np.uint64(cm)) == np.uint64(cm)
+        w[sel] = tmp[sel]
+      check(lambda: st.apply_bits(cm, tgt_bit, g), ref, ('apply_bits', cbits, tgt_bit))
