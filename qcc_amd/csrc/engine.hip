@@ -321,11 +321,12 @@ int use_device(qh_state_s *h) {
 // grouped send/recv completes only when every peer has posted its half): if a peer is missing, or the ranks disagree
 // about a round, a plain hipStreamSynchronize never returns.  Such handles poll instead and give up after
 // QH_COMM_TIMEOUT_MS (default 300 s): QH_ERR_COMM, the handle poisoned -- an error line instead of a hung job.
-int comm_timeout_ms() {
-  static int v = env_int("QH_COMM_TIMEOUT_MS", 300000);
-  return v;
+int comm_timeout_ms() { return env_int("QH_COMM_TIMEOUT_MS", 300000); }      // (read at every wait: tests shorten it)
+// QH_COMM_WATCH_ALL=1 (tests): watch every handle that has a communicator, the one-rank loop-back included
+bool watched(const qh_state_s *h) {
+  if (!h->comm || h->comm->dry) return false;
+  return (h->comm->nranks > 1 && !h->comm->custom) || env_int("QH_COMM_WATCH_ALL", 0) != 0;
 }
-bool watched(const qh_state_s *h) { return h->comm && h->comm->nranks > 1 && !h->comm->custom && !h->comm->dry; }
 template <typename Query> int poll_until_done(qh_state_s *h, Query query, const char *what) {
   const auto t0 = std::chrono::steady_clock::now();
   for (unsigned spins = 0;; ++spins) {

@@ -154,3 +154,52 @@ def test_exchange_needs_a_communicator():
     with pytest.raises(native.QhError):
       st.exchange_loopback(12)           # not a local bit
     assert st.exchange_stats()['exchanges'] == 0
+
+
+def test_watched_waits_poll_and_time_out(monkeypatch, oracle):
+  """The watchdog of host waits (engine.hip wait_stream / poll_until_done): handles whose communicator has several RCCL
+  ranks poll their stream instead of blocking, and give up with QH_ERR_COMM after QH_COMM_TIMEOUT_MS -- a missing peer
+  or a mismatched round is an error message, not a hung job (VERDICT r3 #1a).  No second GPU here, so the one-rank
+  loop-back is watched too (QH_COMM_WATCH_ALL=1): (1) the polling path returns the right amplitudes and geometry
+  record, (2) with the timeout at zero a wait behind 28-qubit sweeps gives up at once, the handle refuses further work
+  until it is re-initialised."""
+  monkeypatch.setenv('QH_COMM_WATCH_ALL', '1')
+  n, bit = 20, 17
+  ops, g8 = workloads.qft_stream(range(n)).arrays()
+  x_ops, x_g = _x_on_bit(n, bit)
+  want = np.zeros(1 << n, dtype=np.complex128)
+  want[9] = 1
+  for o, g in ((ops, g8), (x_ops, x_g), (ops, g8)):
+    oracle.run_stream(want, n, o, g)
+  with device.DeviceState(n, 128, fusion=native.QH_FUSE_SWEEP) as st:
+    st.comm_init(1, 0, device.DeviceState.comm_unique_id())
+    st.init_basis(9)
+    st.run_stream(ops, g8)
+    st.exchange_loopback(bit, 1 << 12)
+    st.run_stream(ops, g8)
+    st.sync()                                   # polled
+    geo = st.exchange_geometry()
+    assert geo['signature'] != 0 and geo['slabs'] * geo['rounds_per_slab'] * geo['peers'] << geo['chunk_bits'] == 1 << n
+    assert geo['staging_bytes'] == (4 if geo['packed'] else 2) * geo['peers'] * (16 << geo['chunk_bits'])
+    assert np.max(np.abs(st.download() - want)) < 1e-11
+  n = 28
+  ops, g8 = workloads.qft_stream(range(n)).arrays()
+  with device.DeviceState(n, 128, fusion=native.QH_FUSE_SWEEP) as st:
+    st.comm_init(1, 0, device.DeviceState.comm_unique_id())
+    st.init_basis(3)
+    st.sync()
+    monkeypatch.setenv('QH_COMM_TIMEOUT_MS', '0')
+    for _ in range(8):
+      st.run_stream(ops, g8)
+      st.flush()
+    with pytest.raises(native.QhError) as ei:   # ~35 ms of sweeps are queued: the watched wait gives up first
+      st.sync()
+    assert ei.value.code == native.QH_ERR_COMM and 'still waiting' in str(ei.value)
+    monkeypatch.setenv('QH_COMM_TIMEOUT_MS', '60000')
+    with pytest.raises(native.QhError):         # poisoned: refuses work ...
+      st.run_stream(ops, g8)
+      st.flush()
+    st.init_basis(3)                            # ... until re-initialised
+    st.run_stream(ops, g8)
+    st.sync()
+    assert abs(st.norm2() - 1) < 1e-10

@@ -250,6 +250,8 @@ def test_device_states_are_reused_across_circuits():
   """qcc_amd.lib.backend's pool (reference call site src/lib/circuit.py:71-101: one qc per experiment):
   a circuit that is closed or collected parks its device state; the next circuit of the same shape gets that handle --
   buffers, second buffer and cached plans included -- and starts from ITS OWN initial state, not from what was left."""
+  import gc
+  gc.collect()                                     # (circuits of earlier tests park their states when they are collected)
   backend.drop_device_pool()
   n = 24
   qc1 = circuit.qc('first')
@@ -258,7 +260,6 @@ def test_device_states_are_reused_across_circuits():
   qc1.maxprob()
   h1 = qc1._dev.h.value
   del qc1                                          # collected -> parked
-  import gc
   gc.collect()
   assert sum(len(v) for v in backend._pool.values()) == 1
   qc2 = circuit.qc('second')

@@ -1,0 +1,21 @@
+#!/bin/bash
+# round 4, GPU session F: layout variants of the group-class islands (same instructions, different placement / stubs)
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/r04f; mkdir -p $O
+cd $R
+for round in 1 2 3; do for lib in before classes3 stubs late stubslate; do for w in qft30 sup30; do
+  echo "## $lib $w round $round" >> $O/ab.txt
+  QCC_HIP_LIB=$R/tools/probes/variants/libqcc_$lib.so QH_SWEEP_TIMING=1 timeout 300 python tools/run_workload.py $w 4 2>&1 | grep -a "qh sweeps\|step ms" | tail -4 >> $O/ab.txt
+done; done; done
+python3 - <<'PY'
+import re, collections, statistics
+cur=None; data=collections.defaultdict(list); per=collections.defaultdict(list)
+for l in open('gpurun_out/r04f/ab.txt'):
+    if l.startswith('##'): cur=tuple(l.split()[1:3])
+    elif 'qh sweeps' in l:
+        v=[float(x) for x in re.findall(r'[0-9.]+',l.split(']')[1])]
+        data[cur].append(sum(v)); per[cur].append(v)
+for k in sorted(data, key=lambda k:(k[1],k[0])):
+    n=len(per[k][0]); pp=[p for p in per[k] if len(p)==n]
+    print(k, 'median total ms %.3f  min %.3f  n %d'%(statistics.median(data[k]),min(data[k]),len(data[k])), 'per sweep', [round(statistics.median(x),3) for x in zip(*pp)])
+PY
