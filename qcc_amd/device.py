@@ -98,6 +98,11 @@ class DeviceState:
       self.h = None
 
   def __del__(self):
+    # A state parked in qcc_amd.lib.backend's pool belongs to the pool: when a circuit and its state are collected in one
+    # pass of the cycle collector, BOTH finalizers run -- the circuit's parks the state (and so resurrects it), this one must
+    # then leave the handle alone.  The pool closes what it evicts or drops explicitly.
+    if getattr(self, '_parked', False):
+      return
     try:
       self.close()
     except Exception:  # pylint: disable=broad-except

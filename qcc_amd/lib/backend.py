@@ -113,6 +113,7 @@ def _pool_limits():
 def drop_device_pool():
     for dev in _pool_order:
         try:
+            dev._parked = False
             dev.close()
         except Exception:  # pylint: disable=broad-except
             pass
@@ -134,11 +135,13 @@ def release_device_state(dev):
     except Exception:  # pylint: disable=broad-except
         dev.close()
         return
+    dev._parked = True            # (DeviceState.__del__ leaves parked states alone)
     _pool.setdefault((dev.nbits, dev.bit_width), []).append(dev)
     _pool_order.append(dev)
     while len(_pool_order) > keep:
         old = _pool_order.pop(0)
         _pool[(old.nbits, old.bit_width)].remove(old)
+        old._parked = False
         old.close()
 
 
@@ -146,10 +149,12 @@ def make_device_state(nbits, bit_width):
     if _device_factory is not None:
         return _device_factory(nbits, bit_width)
     parked = _pool.get((nbits, bit_width))
-    if parked:
+    while parked:
         dev = parked.pop()
         _pool_order.remove(dev)
-        return dev            # (its contents are whatever the last circuit left: the caller initialises the state)
+        dev._parked = False
+        if getattr(dev, 'h', None):
+            return dev        # (its contents are whatever the last circuit left: the caller initialises the state)
     try:
         return _default_device_factory(nbits, bit_width)
     except native.QhError as e:

@@ -297,3 +297,71 @@ def test_alias_psi_contract_on_the_stand_in(oracle):
   s0 = qc.psi
   qc.h(1)
   assert not s0.flags.writeable and abs(s0[2]) < 1e-15 and abs(qc.psi[2]) > 0.1
+
+
+def test_device_pool_survives_the_cycle_collector(monkeypatch):
+  """qcc_amd.lib.backend parks the device state of a finished circuit for the next one of the same shape.  A circuit
+  holds reference cycles (its gate lambdas), so it is usually reclaimed by the cycle collector -- which runs the
+  finalizer of the circuit (parks the state, resurrecting it) AND the finalizer of the state in the same pass: the
+  latter must leave a parked handle alone (round 4: it closed it, the next circuit got a dead handle)."""
+  import gc
+  from qcc_amd import device, native
+
+  class FakeLib:
+    def qh_discard_pending(self, h):
+      return 0
+
+    def qh_destroy(self, h):
+      return 0
+
+  class DeviceState(device.DeviceState):            # same finalizer / close() as the real one, no device behind it
+    created = 0
+
+    def __init__(self, nbits, bw):
+      DeviceState.created += 1
+      self.nbits, self.bit_width = nbits, bw
+      self.h, self.lib = object(), FakeLib()
+
+    def init_product(self, factors):
+      assert self.h is not None, 'a closed handle came out of the pool'
+
+    def run_stream(self, ops_, g):
+      pass
+
+    def argmax(self):
+      return 0, 1.0
+
+    def reset_stats(self):
+      pass
+
+  monkeypatch.setattr(native, 'check', lambda rc: None)
+  backend.set_device_factory(None)                  # the pool only serves the default factory
+  monkeypatch.setattr(backend, '_default_device_factory', lambda n, bw: DeviceState(n, bw))
+  backend.drop_device_pool()
+  qc1 = circuit.qc('first')
+  r = qc1.reg(10, 5)
+  qc1.qft(r)
+  qc1.maxprob()
+  first = qc1._dev
+  del qc1
+  gc.collect()
+  assert backend._pool_order == [first] and first.h is not None
+  qc2 = circuit.qc('second')
+  r = qc2.reg(10, 11)
+  qc2.h(r[9])
+  qc2.maxprob()
+  assert qc2._dev is first and DeviceState.created == 1 and not backend._pool_order
+  qc3 = circuit.qc('third')                         # pool empty: a new state
+  qc3.reg(10, 1)
+  qc3.h(0)
+  qc3.maxprob()
+  assert DeviceState.created == 2
+  qc2.close(); qc3.close()
+  assert len(backend._pool_order) == 2
+  monkeypatch.setenv('QCC_POOL_STATES', '1')
+  qc4 = circuit.qc('fourth')
+  qc4.reg(9, 0); qc4.h(0); qc4.maxprob()
+  qc4.close()                                       # a third parked state: the oldest ones are closed
+  assert len(backend._pool_order) == 1 and backend._pool_order[0].nbits == 9
+  backend.drop_device_pool()
+  assert not backend._pool_order and first.h is None
