@@ -155,6 +155,8 @@ def make_device_state(nbits, bit_width):
         dev._parked = False
         if getattr(dev, 'h', None):
             return dev        # (its contents are whatever the last circuit left: the caller initialises the state)
+    if _pool_order and nbits > _pool_limits()[1]:
+        drop_device_pool()    # a state too large to park wants the memory for its own second buffer (relayout sweeps)
     try:
         return _default_device_factory(nbits, bit_width)
     except native.QhError as e:
