@@ -1924,7 +1924,7 @@ inline std::string plan_to_json(const std::vector<GateRec> &queue, int nloc, uin
         s += buf;
         for (uint32_t gi = 0; o.kind == OP_DIAG && gi < o.n_groups; ++gi) {
           const DGroup &g = sp.groups[o.group_off + gi];
-          snprintf(buf, sizeof buf, "%s[%u,%u,%u,%u,%u]", gi ? "," : "", g.lane_mask, g.reg_mask, g.flags, g.ntab, g.n_oterms);
+          snprintf(buf, sizeof buf, "%s[%u,%u,%u,%u,%u,%.17g,%.17g]", gi ? "," : "", g.lane_mask, g.reg_mask, g.flags, g.ntab, g.n_oterms, g.re, g.im);
           s += buf;
         }
         s += "]}";
