@@ -14,6 +14,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <cassert>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -77,7 +78,10 @@ enum : uint32_t { OP_DENSE_REG = 0, OP_DENSE_LANE = 1, OP_DIAG = 2,
 enum : uint32_t { OPF_DEFER_C = 1, OPF_USE_C = 2, OPF_REAL = 4,  // REAL: all four entries real
                   OPF_BFLY = 8, OPF_BFLY_SHIFT = 4,                // unit-entry butterfly, variant in bits 4..6
                   OPF_LANE_DPP = 128, OPF_SWAP_RI = 256,           // lane butterfly by DPP moves; partner re/im exchanged
-                  OPF_GHOST = 1024 };   // planner-internal: the op of a ghost gate (counted by the cost model, removed before the plan leaves)
+                  OPF_GHOST = 1024,     // planner-internal: the op of a ghost gate (counted by the cost model, removed before the plan leaves)
+                  // register butterfly behind a phase c (1 + i) / c (1 - i) on the slots with its target bit set (a T or T^+
+                  // waiting for it: fused, tools/gen_sweep_asm.py L_bfr*); the real scale c travels in g[0]
+                  OPF_ROT_P = 2048, OPF_ROT_M = 4096 };
 
 // Gates of the form c*M with every entry of M in {1,-1,i,-i} (h, yroot, v = sqrt-x and
 // their adjoints: ops.py:130-132,152-162) cost additions only once the scalar c is moved
@@ -591,6 +595,7 @@ class Planner {
   bool defer_diag_ = env_flag("QH_DEFER_DIAG", true);   // see build_sweep
   bool lookahead_ = env_flag("QH_RELAYOUT_AHEAD", true); // see finish_relayout
   bool reorder_ = env_flag("QH_REORDER", true);                    // see reorder_for_fewer_swaps
+  bool rot_fuse_ = env_flag("QH_ROT_FUSE", true);                 // a pi/4-type phase on a butterfly's target rides in the butterfly (emit_ops_with)
   bool lswap_early_ = env_flag("QH_LSWAP_EARLY", true);            // lane <-> register exchange before the phases of its gate (emit_ops_with)
   std::vector<uint64_t> alg_override_;
   std::vector<uint32_t> weight_;  // reference gate applications each pending record stands for
@@ -1410,6 +1415,29 @@ class Planner {
           lswap(l0, vr);
           swaps.push_back(Swap{0, l0, vr});
         }
+        // A phase waiting on the butterfly's own target bit alone -- diag(1, phi) with phi = c (1 +- i), c real: T, T^+
+        // and their odd powers -- does not become a DIAG group (an op and a group dispatch, a complex product on half the
+        // slots): the butterfly takes it along (OPF_ROT_*: an addition and an fma per slot, c folded into its own fma
+        // constants).  Register butterflies of complex128 tiles only; diagonal terms commute, so taking this one out of
+        // the pending set changes nothing else.
+        uint32_t rot_flags = 0;
+        double rot_c = 0.0;
+        {
+          const int lnow = lane_index(geom, r->tgt);
+          const bool to_reg = lnow < 0 || (lnow >= 4 && ch.lswap > 0);
+          if (rot_fuse_ && bv >= 0 && to_reg && amp_bytes_ == 16 && !r->ghost)
+            for (size_t k = 0; k < pending.size(); ++k) {
+              const PTerm &t = pending[k];
+              if (t.mask != (1ull << r->tgt)) continue;
+              const double ar = std::fabs(t.re), ai = std::fabs(t.im);
+              if (ar > 0.0 && std::fabs(ar - ai) <= 4e-16 * ar) {
+                rot_c = 0.5 * (ar + ai) * (t.re < 0 ? -1.0 : 1.0);
+                rot_flags = ((t.re < 0) == (t.im < 0)) ? OPF_ROT_P : OPF_ROT_M;
+                pending.erase(pending.begin() + (long)k);
+              }
+              break;
+            }
+        }
         const size_t n_ops_before = sp->ops.size();
         flush_diag(&pending, 1ull << r->tgt, sp, geom);
         // non-zero only when THIS flush emitted a DIAG op right in front of the dense op
@@ -1451,6 +1479,13 @@ class Planner {
         if (bv >= 0) {
           op.flags = OPF_BFLY | ((uint32_t)bv << OPF_BFLY_SHIFT);
           memset(op.g, 0, sizeof op.g);
+          if (rot_flags) {
+            assert(op.kind == OP_DENSE_REG);     // (to_reg above: the target sits in a register by now)
+            op.flags |= rot_flags;
+            op.g[0] = rot_c;
+            sp->ops.push_back(op);
+            continue;
+          }
           if (bv == 1) { op.g[0] = -1.0; op.g[1] = 1.0; }        // LDS lane form: new = own + beta*partner,
           else if (bv == 2) { op.g[0] = 1.0; op.g[1] = -1.0; }   // beta on the 0-lane / on the 1-lane
           int *budget = (li < 0 || li >= 4) ? nullptr : one_step_dpp((uint32_t)li) ? &ch.dpp01 : &ch.dpp23;

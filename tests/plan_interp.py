@@ -14,6 +14,7 @@ from qcc_amd import native
 
 OP_DENSE_REG, OP_DENSE_LANE, OP_DIAG, OP_LSWAP, OP_WSWAP = 0, 1, 2, 3, 4
 OPF_REAL, OPF_BFLY, OPF_LANE_DPP, OPF_SWAP_RI = 4, 8, 128, 256
+OPF_ROT_P, OPF_ROT_M = 2048, 4096      # register butterfly behind the phase g[0] * (1 +- i) on its target
 DG_LTAB = 1
 DG_BITFAC = 8
 
@@ -178,6 +179,9 @@ def run_plan(psi, sweeps, nloc, shard=0):
           psi[ok] = new.astype(psi.dtype)[ok]
           continue
         m = _BFLY[v]
+        if flags & (OPF_ROT_P | OPF_ROT_M):
+          assert kind != OP_DENSE_LANE and int(op['cm_reg']) == 0 and int(op['cm_thread']) == 0
+          m = m @ np.diag([1.0, g8[0] * (1 + 1j if flags & OPF_ROT_P else 1 - 1j)])
       else:
         m = g8.view(np.complex128).reshape(2, 2)
       lo = ok & ~_bit(idx, tgt)

@@ -59,7 +59,9 @@ def price(sw, rb=5):
   for op in sw['ops']:
     k, f = op['kind'], op['flags']
     if k == 0:
-      if f & OPF_BFLY:
+      if f & OPF_BFLY and f & (2048 | 4096):
+        cost['register butterflies behind a pi/4 phase (fused)'] += 3 * nr
+      elif f & OPF_BFLY:
         cost['register butterflies'] += 2 * nr
       elif f & OPF_REAL:
         cost['dense real (register)'] += 5 * nr

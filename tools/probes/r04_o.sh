@@ -1,13 +1,12 @@
 #!/bin/bash
-# round 4, GPU session O: the argument block of k_sweep (one bulk fetch instead of 17 scalar round trips) and the slot-offset
-# prefetch of the islands: parity first, then interleaved A/B against the previous build (tools/probes/variants/libqcc_hip_base.so)
+# round 4, GPU session O: parity, then interleaved A/B of the library at HEAD against tools/probes/variants/libqcc_hip_base.so
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r04o; mkdir -p $O
 cd $R
 timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_gpu_relayout.py tests/test_gpu_sharded.py tests/test_gpu_exchange.py -x -q -m gpu > $O/tests.log 2>&1
 grep -a -E "passed|failed|error" $O/tests.log | tail -3
-W=${WORKLOADS:-"qft30 sup30 qft30c64 qft33 grover34"}
-for round in 1 2 3; do for v in new base new_ltab; do for w in $W; do
+W=${WORKLOADS:-"sup30 qft30 qft33 grover34"}
+for round in 1 2 3; do for v in new base; do for w in $W; do
   echo "## $v $w round $round" >> $O/ab.txt
   case $v in
     base) export QCC_HIP_LIB=$R/tools/probes/variants/libqcc_hip_base.so; unset QH_LTAB_ISLAND;;
