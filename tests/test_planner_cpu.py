@@ -147,3 +147,31 @@ def test_supremacy_and_grover_streams_plan_completely():
   ops, g8 = workloads.grover_stream(10, [1, 0] * 5, iterations=1).arrays()
   p = _plan(20, ops, g8)
   assert sum(s['gates'] for s in p['sweeps']) + p['noop_gates'] == len(ops)
+
+
+@pytest.mark.parametrize('name', ['qft30', 'sup30', 'grover34', 'sup16c64'])
+def test_dry_flush_builds_the_device_op_buffers(name):
+  """A flush of a planner-only handle goes through everything but the launches: planning, the device copies of ops and
+  groups (handler numbers, factors folded into op headers, lane-table flags).  Guards the host-side passes over those
+  buffers (a pass that read a header word after another had overwritten it crashed here first)."""
+  lib = native.load()
+  bw = 64 if name.endswith('c64') else 128
+  if name.startswith('qft'):
+    n, sb = 30, workloads.qft_stream(range(30))
+  elif name.startswith('sup'):
+    n = int(name[3:5])
+    sb = workloads.supremacy_stream(n, 20, seed=0)
+  else:
+    n, sb = 34, workloads.grover_stream(17, [1, 0] * 8 + [1], iterations=1)
+  ops, g8 = sb.arrays()
+  g8 = np.ascontiguousarray(g8, dtype=np.float64)
+  h = ctypes.c_void_p()
+  native.check(lib.qh_create_dry(n, bw, ctypes.byref(h)))
+  native.check(lib.qh_set_fusion(h, native.QH_FUSE_SWEEP))
+  for rep in range(2):                 # (the second flush takes the cached plan)
+    for k in range(len(ops)):
+      gp = ctypes.cast(g8.ctypes.data + 64 * k, _dp)
+      c, t = int(ops[k, 0]), int(ops[k, 1])
+      native.check(lib.qh_apply1(h, t, gp) if c == workloads.NO_CTL else lib.qh_applyc(h, c, t, gp))
+    native.check(lib.qh_flush(h))
+  lib.qh_destroy(h)
