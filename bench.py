@@ -341,7 +341,8 @@ def single_shot(device_index):
     for rep in range(3):
       qc = circuit.qc('single-shot')
       reg = qc.reg(n, 0x12CB9A5E3 & ((1 << n) - 1) if rep == 0 else rep)
-      qc.maxprob()                             # state built on the device, engine idle
+      qc.flush()                               # the register is built on the device (qh_init_product: a product register stays
+      qc.sync()                                # a list of factors until something needs the amplitudes), engine idle
       t0 = time.perf_counter()
       qc.qft(reg)
       bits, p = qc.maxprob()

@@ -26,6 +26,7 @@ Host-visible state contract:
     waited for: for code that depends on the aliasing, not for speed.
 """
 import math
+import weakref
 
 import numpy as np
 
@@ -395,11 +396,17 @@ class qc:
         return ctl[0], True
 
     # ------------------------------------------------------------------ gates
+    # The generated gate methods are instance attributes (as in the reference, circuit.py:97-101).  They reach the circuit
+    # through a WEAK reference: a closure over `self` stored on `self` is a cycle, and a circuit in a cycle keeps its
+    # device state -- two 16-GiB buffers at 30 qubits -- until the cycle collector happens to run; `del qc` (or the name
+    # going out of scope) must give the state back to the pool at once (backend.release_device_state).
     def add_single(self, name, gate):
-        setattr(self, name, lambda idx, cond=True: self.apply1(gate, idx, name) if cond else None)
+        ref = weakref.ref(self)
+        setattr(self, name, lambda idx, cond=True: ref().apply1(gate, idx, name) if cond else None)
 
     def add_ctl(self, name, gate):
-        setattr(self, name, lambda idx0, idx1, cond=True: self.applyc(gate, idx0, idx1, name) if cond else None)
+        ref = weakref.ref(self)
+        setattr(self, name, lambda idx0, idx1, cond=True: ref().applyc(gate, idx0, idx1, name) if cond else None)
 
     def apply1(self, gate, idx_set, name=None, *, val=None):
         """Apply a single-qubit gate to one index or to each index of a list/Reg."""
