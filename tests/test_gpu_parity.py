@@ -613,3 +613,73 @@ def test_per_gate_kernel_shapes_every_target_at_22_qubits(oracle, bw):
         sel = (idx & np.uint64(cm)) == np.uint64(cm)
         w[sel] = tmp[sel]
       check(lambda: st.apply_bits(cm, tgt_bit, g), ref, ('apply_bits', cbits, tgt_bit))
+
+
+@pytest.mark.parametrize('n', [13, 15])
+@pytest.mark.parametrize('bw', [128, 64])
+def test_fused_phases_and_inlined_groups_vs_oracle(oracle, bw, n):
+  """Round 4: (a) a T / T^+ / odd multiple of pi/4 waiting on a butterfly's target rides in the butterfly (planner.h
+  OPF_ROT_*, island L_bfr*: every variant x every tile position of the target, both rotations, both signs of the scale),
+  next to phases that must NOT fuse (s, z, a general u1, a phase under a control); (b) DIAG ops of one simple group are
+  folded into their op headers (island L_d1*): sign flips (cz), uniform and lane-masked factors on every one- and two-bit
+  register mask the plan produces, and masks of three bits (ccz-like).  complex64 takes the general paths: same results."""
+  dt = np.complex128 if bw == 128 else np.complex64
+  rng = np.random.default_rng(400 + n)
+  had, yr, v, t8 = gates.hadamard(), gates.yroot(), gates.vgate(), gates.tgate()
+  dag = lambda g: np.conj(np.asarray(g).reshape(2, 2).T)
+  z = np.diag([1.0, -1.0]).astype(np.complex128)
+  bflies = [had, yr, dag(yr), v, dag(v)]
+  phases = [t8, dag(t8), np.asarray(t8).reshape(2, 2) @ np.asarray(t8).reshape(2, 2) @ np.asarray(t8).reshape(2, 2),   # T, T^+, T^3
+            gates.sgate(), z, gates.u1(0.3), -1.0 * np.asarray(t8).reshape(2, 2)]                                # not fused: S, Z, U1; scaled T
+  streams = []
+  for t in range(n):                       # every position of the target: lanes, registers, wave bits
+    s = [(NO_CTL, q, had) for q in range(n)]
+    for k, b in enumerate(bflies):
+      s += [(NO_CTL, t, phases[(t + k) % len(phases)]), (NO_CTL, t, b)]
+    s += [((t + 1) % n, t, t8), (NO_CTL, t, v)]                  # a controlled T is a two-bit phase: stays a group
+    streams.append(s)
+  for a in range(0, n, 2):                 # single groups: cz on every pair class, phases on single bits, three-bit masks
+    s = [(NO_CTL, q, [had, v, yr][q % 3]) for q in range(n)]
+    for b in range(n):
+      if b != a:
+        s += [(a, b, z), (NO_CTL, (a + b) % n, [had, v][b % 2])]
+    s += [(NO_CTL, a, gates.rz(0.4 + a)), (NO_CTL, (a + 1) % n, had), (NO_CTL, a, gates.u1(0.2)), (NO_CTL, (a + 2) % n, yr)]
+    streams.append(s)
+  worst = 0.0
+  with device.DeviceState(n, bw, fusion=native.QH_FUSE_SWEEP) as st:
+    for stream in streams:
+      psi0 = _rand_state(rng, n, dt)
+      want = psi0.copy()
+      for c, t, g in stream:
+        g = np.asarray(g, dtype=dt).reshape(4)
+        if c == NO_CTL:
+          oracle.apply1(want, g, n, t)
+        else:
+          oracle.applyc(want, g, n, c, t)
+      st.upload(psi0)
+      for c, t, g in stream:
+        if c == NO_CTL:
+          st.apply1(g, t)
+        else:
+          st.applyc(g, c, t)
+      worst = max(worst, float(np.max(np.abs(st.download() - want))))
+    # three-bit register masks (the "any other mask" handlers): doubly-controlled z / phase on register-bit qubits
+    masks = native.load()
+    psi0 = _rand_state(rng, n, dt)
+    want = psi0.copy()
+    st.upload(psi0)
+    idx = np.arange(1 << n, dtype=np.uint64)
+    for (qa, qb, qc), ph in (((n - 8, n - 9, n - 10), -1.0), ((n - 7, n - 9, n - 11), np.exp(0.7j)), ((n - 8, n - 10, n - 11), -1.0)):
+      sel = np.ones(1 << n, dtype=bool)
+      cm = 0
+      for q_ in (qa, qb):
+        sel &= ((idx >> np.uint64(n - 1 - q_)) & np.uint64(1)).astype(bool)
+        cm |= 1 << (n - 1 - q_)
+      sel &= ((idx >> np.uint64(n - 1 - qc)) & np.uint64(1)).astype(bool)
+      want[sel] *= dt(ph) if bw == 64 else ph
+      g8 = np.array([1, 0, 0, 0, 0, 0, np.real(ph), np.imag(ph)], dtype=np.float64)
+      native.check(masks.qh_apply_bits(st.h, cm, n - 1 - qc, g8.ctypes.data_as(ctypes.POINTER(ctypes.c_double))))
+      st.apply1(had, (qa + 3) % n)
+      oracle.apply1(want, np.asarray(had, dtype=dt).reshape(4), n, (qa + 3) % n)
+    worst = max(worst, float(np.max(np.abs(st.download() - want))))
+  assert worst <= (TOL if bw == 128 else 3e-6), worst
