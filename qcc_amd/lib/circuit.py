@@ -129,6 +129,13 @@ class _LazyPsi(np.lib.mixins.NDArrayOperatorsMixin):
         return repr(self._get())
 
 
+def _alive(ref):
+    circ = ref()
+    if circ is None:      # (a gate method kept beyond its circuit: `f = qc.h; del qc; f(0)`)
+        raise ReferenceError('this gate method belongs to a circuit that has been released')
+    return circ
+
+
 class qc:
     """State + gate application + (optional) IR recording."""
 
@@ -402,11 +409,11 @@ class qc:
     # going out of scope) must give the state back to the pool at once (backend.release_device_state).
     def add_single(self, name, gate):
         ref = weakref.ref(self)
-        setattr(self, name, lambda idx, cond=True: ref().apply1(gate, idx, name) if cond else None)
+        setattr(self, name, lambda idx, cond=True: _alive(ref).apply1(gate, idx, name) if cond else None)
 
     def add_ctl(self, name, gate):
         ref = weakref.ref(self)
-        setattr(self, name, lambda idx0, idx1, cond=True: ref().applyc(gate, idx0, idx1, name) if cond else None)
+        setattr(self, name, lambda idx0, idx1, cond=True: _alive(ref).applyc(gate, idx0, idx1, name) if cond else None)
 
     def apply1(self, gate, idx_set, name=None, *, val=None):
         """Apply a single-qubit gate to one index or to each index of a list/Reg."""
