@@ -343,7 +343,14 @@ def test_device_pool_survives_the_cycle_collector(monkeypatch):
   qc1.qft(r)
   qc1.maxprob()
   first = qc1._dev
-  del qc1
+  # the generated gate methods hold the circuit weakly (no reference cycle): dropping the last name parks the state AT
+  # ONCE -- a circuit waiting for the cycle collector kept two 16-GiB buffers and the next circuit allocated afresh
+  gc.disable()
+  try:
+    del qc1, r
+    assert backend._pool_order == [first] and first.h is not None, 'the circuit was not released by reference counting'
+  finally:
+    gc.enable()
   gc.collect()
   assert backend._pool_order == [first] and first.h is not None
   qc2 = circuit.qc('second')
