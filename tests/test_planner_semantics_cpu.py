@@ -79,7 +79,7 @@ def _planned(n, nloc, shard, stream, bw=128):
 
 
 ENVS = [{}, {'QH_WAVE_BITS': '2'}, {'QH_WAVE_BITS': '0'}, {'QH_LANE_VALU': '2'}, {'QH_LANE_VALU': '2', 'QH_WAVE_BITS': '2'},
-        {'QH_STORE_SWAPPED': '0'}, {'QH_DEFER_DIAG': '0', 'QH_BFLY': '0'}, {'QH_SWEEP_RB': '3'}, {'QH_SPLIT_LANES': '0'}, {'QH_PROPAGATE_X': '0'}]
+        {'QH_STORE_SWAPPED': '0'}, {'QH_DEFER_DIAG': '0', 'QH_BFLY': '0'}, {'QH_SWEEP_RB': '3'}, {'QH_SPLIT_LANES': '0'}, {'QH_PROPAGATE_X': '0'}, {'QH_ROT_FUSE': '0'}]
 
 
 @pytest.mark.parametrize('env', ENVS, ids=lambda e: ','.join(f'{k[3:]}={v}' for k, v in e.items()) or 'default')
