@@ -886,15 +886,7 @@ int qh_init_product(qh_handle h, int nfactors, const int *nq, const double *cons
     }
     if (all_basis && total == h->nglob) return qh_init_basis(h, index);
   }
-  reset_layout_for_init(h);
-  qh::ProductSpec sp{};
-  sp.nf = nfactors;
-  sp.nglob = h->nglob;
-  sp.identity = 1;
-  for (int b = 0; b < h->nglob; ++b) {
-    sp.perm[b] = (uint8_t)h->perm[b];
-    if (h->perm[b] != b) sp.identity = 0;
-  }
+  // (validation first: a call that fails must leave the handle -- layout, queue -- exactly as it found it)
   int total = 0;
   uint64_t entries = 0;
   for (int f = 0; f < nfactors; ++f) {
@@ -910,8 +902,17 @@ int qh_init_product(qh_handle h, int nfactors, const int *nq, const double *cons
   }
   if (total != h->nglob) return fail(QH_ERR_ARG, "factor sizes do not add up to the number of qubits");
   if (entries > (1ull << 25)) return fail(QH_ERR_ARG, "factor tables larger than 2^25 amplitudes");
+  reset_layout_for_init(h);
   h->queue.clear();
   h->poisoned = false;
+  qh::ProductSpec sp{};
+  sp.nf = nfactors;
+  sp.nglob = h->nglob;
+  sp.identity = 1;
+  for (int b = 0; b < h->nglob; ++b) {
+    sp.perm[b] = (uint8_t)h->perm[b];
+    if (h->perm[b] != b) sp.identity = 0;
+  }
   if (h->dry) return QH_OK;
   if (h->comm) qh::wait_all_arrivals(&h->comm->arrivals, h->stream);
   std::vector<double> tab(2 * std::max<uint64_t>(entries, 1));

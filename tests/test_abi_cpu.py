@@ -107,6 +107,42 @@ def test_bitmap_roundtrip_dry(lib):
   lib.qh_destroy(h)
 
 
+def test_failed_init_product_leaves_the_layout_alone_dry(lib):
+  """qh_init_product reset the bit map BEFORE validating; an error return then scrambled a live state."""
+  h = ctypes.c_void_p()
+  assert lib.qh_create_dry(10, 128, ctypes.byref(h)) == 0
+  assert lib.qh_remap_swap(h, 3, 8) == 0 and lib.qh_remap_swap(h, 4, 9) == 0
+  assert lib.qh_set_fusion(h, native.QH_FUSE_SWEEP) == 0
+  def bitmap():
+    bm = (ctypes.c_int32 * 64)()
+    assert lib.qh_get_bitmap(h, bm) == 0
+    return list(bm)[:10]
+  before = bitmap()
+  assert before != list(range(10))
+  had = (ctypes.c_double * 8)(*(np.array([1, 1, 1, -1], dtype=np.complex128) / np.sqrt(2)).view(np.float64))
+  assert lib.qh_apply1(h, 2, had) == 0
+  pend = ctypes.c_uint64()
+  assert lib.qh_pending_gates(h, ctypes.byref(pend)) == 0 and pend.value == 1
+  # factor sizes that do not add up, an out-of-range basis index, a basis factor without basis[]: all refused ...
+  tab = np.array([0.6, 0.8j], dtype=np.complex128)
+  for nq, amps, basis in (([4, 4], [None, None], [1, 2]), ([5, 5], [None, None], [1, 99]), ([1, 8], [tab.ctypes.data, None], [0, 7])):
+    c_nq = (ctypes.c_int32 * len(nq))(*nq)
+    c_amps = (ctypes.c_void_p * len(nq))(*amps)
+    c_basis = (ctypes.c_uint64 * len(nq))(*basis)
+    assert lib.qh_init_product(h, len(nq), c_nq, c_amps, c_basis) == native.QH_ERR_ARG
+    # ... and nothing moved: same bit map, the queued gate still queued
+    assert bitmap() == before
+    assert lib.qh_pending_gates(h, ctypes.byref(pend)) == 0 and pend.value == 1
+  # a valid call replaces the state: canonical order, empty queue
+  c_nq = (ctypes.c_int32 * 2)(1, 9)
+  c_amps = (ctypes.c_void_p * 2)(tab.ctypes.data, None)
+  c_basis = (ctypes.c_uint64 * 2)(0, 7)
+  assert lib.qh_init_product(h, 2, c_nq, c_amps, c_basis) == 0
+  assert bitmap() == list(range(10))
+  assert lib.qh_pending_gates(h, ctypes.byref(pend)) == 0 and pend.value == 0
+  lib.qh_destroy(h)
+
+
 def test_libq_facade_header_links(tmp_path, lib):
   """include/libq.h: every declared function resolves against libqcc_hip.so (link only)."""
   import re
