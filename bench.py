@@ -225,6 +225,32 @@ def timed_steps(eng, ops, g8, steps, warmup, dist):
   return wall, ev_ms, st
 
 
+def sharded_parity(eng, n, x, ops, g8, dist, samples=64):
+  """Correctness evidence INSIDE the multi-GPU line (the first run on several GPUs is a test, not only a number): the
+  state is re-initialised, ONE QFT runs through the same path as the timed steps -- sweeps, exchange over the links,
+  sweeps -- and every rank compares `samples` of the amplitudes it holds with the closed form of the QFT of a basis
+  state (workloads.qft_analytic: exp(2 pi i bitrev(x) k / N) / sqrt(N)); the largest error over all ranks comes back.
+  A misplaced block keeps the norm and fails this."""
+  import torch
+  from qcc_amd import workloads
+  eng.init_basis(x)
+  eng.run_stream(ops, g8)
+  eng.flush()
+  eng.sync()
+  rng = np.random.default_rng(1234 + eng.rank)
+  nloc = eng.nloc
+  # physical indices inside this rank's shard, spread over its blocks (the blocks another rank sent are the interesting ones)
+  local = rng.integers(0, 1 << nloc, size=samples, dtype=np.uint64)
+  local[:8] = [0, (1 << nloc) - 1, 1, 1 << (nloc - 1), (1 << (nloc - 1)) - 1, 1 << (nloc - 2), 3 << (nloc - 2), 5][:8]
+  logical = [eng.phys_to_logical((eng.rank << nloc) | int(v)) for v in local]
+  got = np.array([eng.amplitude_local(k) for k in logical], dtype=np.complex128)
+  want = workloads.qft_analytic(n, x, np.array(logical, dtype=np.uint64))
+  err = float(np.max(np.abs(got - want)))
+  t = torch.tensor([err], dtype=torch.float64, device=eng._red_device())
+  dist.all_reduce(t, op=dist.ReduceOp.MAX)
+  return float(t.item())
+
+
 def ladder_base(device_index, fusion, steps=3):
   """The N=1 point of BASELINE config 5's ladder (33/34/35/36 qubits on 1/2/4/8 GPUs, 2^33
   amplitudes = 128 GiB per GPU): a 33-qubit QFT on this GPU, outside the headline's timed region."""
@@ -406,8 +432,19 @@ def main():
             'config': {'workload': f'{n}-qubit QFT complex128 (failed before a result)', 'qubits': n},
             'error': msg, 'error_stage': stage, 'error_rank': rank,
             'exchange_path': getattr(eng, 'exchange_path', None)}
-    print(json.dumps(line), flush=True)
-    os._exit(3)
+    # ONE line on stdout: rank 0 prints it (errors of this kind are raised on every rank by design: TransportError, geometry
+    # mismatch, watchdog); another rank prints only when it fails alone -- rank 0 is then stuck or gone and cannot speak.
+    alone = bool(getattr(exc, 'local_only', False))
+    if rank == 0 or alone:
+      print(json.dumps(line), flush=True)
+    try:
+      if eng is not None:
+        eng.eng.close() if hasattr(eng, 'eng') else eng.close()
+    except Exception:  # pylint: disable=broad-except
+      pass
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os._exit(3)          # (no destroy_process_group: peers may be stuck in a collective that will never complete)
 
   dist = None
   eng = None
@@ -434,9 +471,19 @@ def main():
       raise
     fail_line('timed steps', e, eng)
 
-  # parity guard inside the bench: closed form on sampled amplitudes after the
-  # first full QFT is checked in tests; here we check the norm (cheap, device-side)
+  # parity guard inside the bench: the norm (cheap, device-side) and -- with several ranks -- sampled amplitudes of one
+  # more QFT against the closed form (a single-GPU run is covered by the GPU tests, which check every amplitude)
   norm2 = eng.norm2_global() if dist is not None else eng.norm2()
+  parity = None
+  if dist is not None:
+    try:
+      parity = sharded_parity(eng, n, x, ops, g8, dist)
+    except Exception as e:  # pylint: disable=broad-except
+      fail_line('parity check after the timed steps', e, eng)
+    if not parity <= 1e-10:
+      fail_line('parity check after the timed steps',
+                RuntimeError(f'max |amplitude - closed form| over {world} ranks x 64 samples = {parity:.3e} > 1e-10 '
+                             f'(norm2 {norm2:.15f}): amplitudes are misplaced or wrong'), eng)
   cached = None
   if (world == 1 and dist is None and fusion != native.QH_FUSE_OFF and os.environ.get('QH_PLAN_CACHE') == '0'
       and not args.no_cached_plan):
@@ -505,6 +552,11 @@ def main():
       out['exchange_path'] = stats.get('exchange_path')
       out['exchange_geometry'] = stats.get('exchange_geometry')     # slabs, rounds, chunk, packed / direct, staging bytes (rank 0)
       out['relayout_on_every_rank'] = getattr(eng, 'relayout', None)
+      out['parity_max_abs'] = parity                                   # vs the closed form, 64 amplitudes per rank, tolerance 1e-10
+      out['parity_samples_per_rank'] = 64
+      out['rccl_ranks'] = stats.get('comm_ranks_reported')             # what the communicator itself reports
+      out['exchange_geometry_checks'] = stats.get('exchange_geometry_checks')
+      out['exchange_verified'] = bool(world == 1 or (stats.get('exchange_geometry_checks') or 0) > 0)
       if stats.get('exchange_seconds', 0.0) > 0:
         out['xgmi_GBps_per_rank'] = stats.get('exchanged_bytes', 0) / stats['exchange_seconds'] / 1e9
   if dist is not None:

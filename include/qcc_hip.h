@@ -185,6 +185,12 @@ typedef struct {
   double span_ms;            /* HIP-event time from the first send to the last landing     */
   uint64_t rounds_packed;    /* rounds moved through the gather / scatter kernels (blocks
                                 without long contiguous runs: after relayout sweeps)       */
+  uint64_t geometry_checks;  /* exchange geometries whose signature was compared with every
+                                peer's and found equal (0 with one rank)                   */
+  uint32_t comm_ranks;       /* size and ...                                               */
+  uint32_t comm_rank;        /* ... rank as the TRANSPORT reports them (ncclCommCount /
+                                ncclCommUserRank; the caller's arguments on the host-staged
+                                transport)                                                 */
 } qh_xstats;
 /* How the last qh_exchange_* call of a handle was cut.  Every field must be the same on every rank (the planner keeps
  * rank-dependent gates as ghosts so that it is; `signature` is what the ranks compare before data moves): tools and tests
@@ -270,8 +276,9 @@ int qh_plan_json(qh_handle h, char *buf, uint64_t cap, uint64_t *needed);
  * 0x51485033, sweeps, gates dropped as no-ops), 64 bytes final_pos (position after the flush of
  * the index bit at each position before it), then per sweep 28 x i64 (rb, regpos[6],
  * regpos_store[6], lanehi[3], nwave, wavepos[2], fixed_ones, ntiles, #ops, #groups, #oterms,
- * #table doubles, #lane tables, lane_low, relayout), 64 bytes dest_pos, 5 x i64 (lanehi and wavepos
- * at store time), 25 x i64 (relayout store as the kernel gets it: reg_dest[6], wave_dest[2], number of
+ * #table doubles, #lane tables, lane_low, relayout), 64 bytes dest_pos, 20 x i64 (seat[6]: the index
+ * bit on each lane bit when the tile is loaded, seat_store[6]: when it is stored, seat_dest[6]: the
+ * position 0..5 a relayout store sends it to, wavepos at store time [2]), 25 x i64 (relayout store as the kernel gets it: reg_dest[6], wave_dest[2], number of
  * unit-index runs, 8 masks, 8 shifts), followed by the SweepOp / DGroup / OTerm / table arrays of
  * qcc_amd/csrc/planner.h, each padded to 8 bytes.  For tools and tests that check a plan
  * without a GPU (tests/plan_interp.py executes it with NumPy).                 */

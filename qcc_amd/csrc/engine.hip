@@ -18,6 +18,7 @@
 #include <cstring>
 #include <ctime>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/qcc_hip.h"
@@ -58,6 +59,11 @@ struct qh_state_s {
   void *host_psi = nullptr;    // qh_create_host_mapped: the pinned, GPU-visible host allocation d_psi points into
   void *d_alt = nullptr;       // second buffer of the same size: target of relayout sweeps (lazily allocated)
   int relayout = -1;           // -1 undecided, 0 off (attached memory, no room, QH_RELAYOUT=0), 1 on
+  // The second buffer of a large owning handle is requested by a helper thread the moment the handle is created (a 16-GiB
+  // allocation takes 0.2 ms - 3 s, contiguous ones longer): register construction, gate submission and planning overlap it,
+  // and the first flush that wants the buffer only waits for what is left (alloc_second_buffer joins).
+  std::thread alt_thread;
+  void *alt_early = nullptr;   // what the helper got (nullptr: refused)
   bool owns_mem = false, owns_stream = false, dry = false;
   bool poisoned = false;       // a sweep of a flush failed after others had run: the amplitudes are undefined until re-initialised
   hipStream_t stream = nullptr;
@@ -77,14 +83,6 @@ struct qh_state_s {
 };
 
 namespace {
-
-int grid_cap() {
-  static int cap = [] {
-    const char *s = getenv("QH_GRID_CAP");
-    return s ? atoi(s) : 0;
-  }();
-  return cap;
-}
 
 template <typename R> qh::Gate2<R> to_gate(const double g[8]) {
   qh::Gate2<R> o;
@@ -106,8 +104,6 @@ qh::BitIns make_ins(uint64_t ones_mask, int zero_pos) {
 unsigned pick_grid(uint64_t nwork, int per_block) {
   uint64_t blocks = (nwork + per_block - 1) / per_block;
   if (blocks < 1) blocks = 1;
-  const int cap = grid_cap();
-  if (cap > 0 && blocks > (uint64_t)cap) blocks = cap;
   // HIP refuses launches of 2^32 threads or more (a per-gate kernel over a 2^33-amplitude shard
   // would be 2^24 blocks of 256): the kernels are grid-stride, so cap the grid
   if (blocks > (1ull << 23)) blocks = 1ull << 23;
@@ -120,8 +116,6 @@ int env_int(const char *name, int dflt) {
 }
 // Launch shape of the per-gate kernels (tools/membench on MI355X): small blocks
 // of work, one chunk per block (no grid-stride), non-temporal access.
-int gate_u() { static int v = env_int("QH_GATE_U", 1); return v; }
-bool gate_nt() { static int v = env_int("QH_GATE_NT", 1); return v != 0; }
 
 template <typename R, int U, bool NT>
 void launch_pair_u(qh_state_s *h, uint64_t nwork, int p, const qh::BitIns &ins, const double g[8],
@@ -136,8 +130,6 @@ void launch_pair_u(qh_state_s *h, uint64_t nwork, int p, const qh::BitIns &ins, 
                        (A *)h->d_psi, nwork, p, ins, to_gate<R>(g), lowpred);
 }
 // Launch shapes of the per-gate kernels, chosen by measurement (tools/membench/pairbench.hip, profiles/r04/):
-// QH_GATE_SHAPE=0 keeps the round-3 shape everywhere (one item per thread, 256-thread blocks) for A/B runs.
-int gate_shape() { static int v = env_int("QH_GATE_SHAPE", 1); return v; }
 int log2_u64(uint64_t v) { int g = 0; while ((1ull << g) < v) ++g; return g; }
 bool tile_fits(uint64_t nwork, int per_block) {     // full tiles only (DPP partner fetch and the block rotation need them)
   return nwork >= (uint64_t)per_block && nwork % per_block == 0 && ((nwork / per_block) & (nwork / per_block - 1)) == 0 &&
@@ -163,26 +155,15 @@ void launch_pair_line(qh_state_s *h, uint64_t namps, const qh::BitIns &ins1, con
 template <typename R>
 void launch_pair(qh_state_s *h, uint64_t nwork, int p, const qh::BitIns &ins, const qh::BitIns &ins1, const double g[8],
                  uint32_t lowpred) {
-  if (gate_shape() && gate_nt()) {
-    if (p < 3 && tile_fits(2 * nwork, 64 * 8 * 4)) {
-      if (p == 0) launch_pair_line<R, 0>(h, 2 * nwork, ins1, g, lowpred);
-      else if (p == 1) launch_pair_line<R, 1>(h, 2 * nwork, ins1, g, lowpred);
-      else launch_pair_line<R, 2>(h, 2 * nwork, ins1, g, lowpred);
-      return;
-    }
-    if (p >= 3 && p <= 8 && tile_fits(nwork, 64 * 8 * 4)) return launch_pair_tile<R, 8, 4>(h, nwork, p, ins, g, lowpred);
-    if (p >= 20 && p <= 25 && tile_fits(nwork, 64 * 16 * 2)) return launch_pair_tile<R, 16, 2>(h, nwork, p, ins, g, lowpred);
+  if (p < 3 && tile_fits(2 * nwork, 64 * 8 * 4)) {
+    if (p == 0) launch_pair_line<R, 0>(h, 2 * nwork, ins1, g, lowpred);
+    else if (p == 1) launch_pair_line<R, 1>(h, 2 * nwork, ins1, g, lowpred);
+    else launch_pair_line<R, 2>(h, 2 * nwork, ins1, g, lowpred);
+    return;
   }
-  const int u = gate_u();
-  if (gate_nt()) {
-    if (u >= 4) launch_pair_u<R, 4, true>(h, nwork, p, ins, g, lowpred);
-    else if (u == 2) launch_pair_u<R, 2, true>(h, nwork, p, ins, g, lowpred);
-    else launch_pair_u<R, 1, true>(h, nwork, p, ins, g, lowpred);
-  } else {
-    if (u >= 4) launch_pair_u<R, 4, false>(h, nwork, p, ins, g, lowpred);
-    else if (u == 2) launch_pair_u<R, 2, false>(h, nwork, p, ins, g, lowpred);
-    else launch_pair_u<R, 1, false>(h, nwork, p, ins, g, lowpred);
-  }
+  if (p >= 3 && p <= 8 && tile_fits(nwork, 64 * 8 * 4)) return launch_pair_tile<R, 8, 4>(h, nwork, p, ins, g, lowpred);
+  if (p >= 20 && p <= 25 && tile_fits(nwork, 64 * 16 * 2)) return launch_pair_tile<R, 16, 2>(h, nwork, p, ins, g, lowpred);
+  launch_pair_u<R, 1, true>(h, nwork, p, ins, g, lowpred);      // one pair per thread, 256-thread blocks (small / ragged states too)
 }
 
 template <typename R, int U, bool NT>
@@ -201,22 +182,13 @@ template <typename R>
 void launch_diag(qh_state_s *h, uint64_t nwork, int sel, const qh::BitIns &ins, double f0r, double f0i,
                  double f1r, double f1i, uint32_t lowpred = 0) {
   using A = typename qh::AmpT<R>::type;
-  if (gate_shape() && gate_nt() && tile_fits(nwork, 64 * 8 * 4)) {
+  if (tile_fits(nwork, 64 * 8 * 4)) {
     const uint64_t blocks = nwork / (64 * 8 * 4);
     hipLaunchKernelGGL((qh::k_diag_tile<R, 8, 4, 3>), dim3((unsigned)blocks), dim3(256), 0, h->stream, (A *)h->d_psi, sel, ins,
                        (R)f0r, (R)f0i, (R)f1r, (R)f1i, lowpred, log2_u64(blocks));
     return;
   }
-  const int u = gate_u() * 2;  // a diagonal work item is one amplitude, a pair item two
-  if (gate_nt()) {
-    if (u >= 4) launch_diag_u<R, 4, true>(h, nwork, sel, ins, f0r, f0i, f1r, f1i, lowpred);
-    else if (u == 2) launch_diag_u<R, 2, true>(h, nwork, sel, ins, f0r, f0i, f1r, f1i, lowpred);
-    else launch_diag_u<R, 1, true>(h, nwork, sel, ins, f0r, f0i, f1r, f1i, lowpred);
-  } else {
-    if (u >= 4) launch_diag_u<R, 4, false>(h, nwork, sel, ins, f0r, f0i, f1r, f1i, lowpred);
-    else if (u == 2) launch_diag_u<R, 2, false>(h, nwork, sel, ins, f0r, f0i, f1r, f1i, lowpred);
-    else launch_diag_u<R, 1, false>(h, nwork, sel, ins, f0r, f0i, f1r, f1i, lowpred);
-  }
+  launch_diag_u<R, 2, true>(h, nwork, sel, ins, f0r, f0i, f1r, f1i, lowpred);   // (a diagonal work item is one amplitude, a pair item two)
 }
 
 // One gate, physical bit positions, one kernel.  Returns QH_* status.
@@ -327,6 +299,28 @@ bool watched(const qh_state_s *h) {
   if (!h->comm || h->comm->dry) return false;
   return (h->comm->nranks > 1 && !h->comm->custom) || env_int("QH_COMM_WATCH_ALL", 0) != 0;
 }
+// A watched wait that gives up must not leave work behind that still writes into the CALLER's memory (the readers' D2H
+// copies of a few bytes, qh_download's buffer) once this call has returned: abort the RCCL communicator -- its kernels
+// then end, whatever the peers do -- and let the handle's streams drain (bounded: 10 s) before the error goes up.  The
+// communicator is gone afterwards (exchanges and all-reduces fail with QH_ERR_COMM); the process should tear the job down.
+void abort_comm_and_drain(qh_state_s *h) {
+  qh::Comm *c = h->comm;
+  if (!c || c->dry) return;
+  if (c->nccl) {
+    (void)qh::rccl().CommAbort(c->nccl);
+    c->nccl = nullptr;
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  for (hipStream_t s : {c->xstream, c->cstream, c->pstream, h->stream}) {
+    if (!s) continue;
+    while (hipStreamQuery(s) == hipErrorNotReady) {
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 10.0) return;
+      struct timespec ts = {0, 200000};
+      nanosleep(&ts, nullptr);
+    }
+  }
+  (void)hipGetLastError();
+}
 template <typename Query> int poll_until_done(qh_state_s *h, Query query, const char *what) {
   const auto t0 = std::chrono::steady_clock::now();
   for (unsigned spins = 0;; ++spins) {
@@ -340,8 +334,10 @@ template <typename Query> int poll_until_done(qh_state_s *h, Query query, const 
       const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
       if (ms > comm_timeout_ms()) {
         h->poisoned = true;
+        abort_comm_and_drain(h);
         return fail(QH_ERR_COMM, "%s: rank %d of %d still waiting after %.0f s (QH_COMM_TIMEOUT_MS): a peer is missing or the "
-                    "ranks disagree about an exchange; the state of this handle is undefined", what, h->comm->rank, h->comm->nranks, ms * 1e-3);
+                    "ranks disagree about an exchange; the communicator was aborted, the state of this handle is undefined", what,
+                    h->comm->rank, h->comm->nranks, ms * 1e-3);
       }
       struct timespec ts = {0, 50000};
       nanosleep(&ts, nullptr);
@@ -401,14 +397,37 @@ hipError_t alloc_state_buffer(void **p, size_t bytes) {
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
   return e;
 }
-bool alloc_second_buffer(qh_state_s *h) {
-  if (h->d_alt) return true;
-  const size_t bytes = (size_t)h->amp_bytes() << h->nloc;
+bool second_buffer_fits(const qh_state_s *h, size_t bytes) {
   size_t fr = 0, total = 0;
   // (a communicator of several ranks will want its staging halves too: up to 4 x (P-1) x chunk amplitudes)
   const size_t reserve = (bytes >> 5) + (3ull << 29) + ((h->comm && h->comm->nranks > 1) ? (4ull << 30) : 0);
-  if (hipMemGetInfo(&fr, &total) == hipSuccess && fr > bytes + reserve &&
-      alloc_state_buffer(&h->d_alt, bytes) == hipSuccess)
+  return hipMemGetInfo(&fr, &total) == hipSuccess && fr > bytes + reserve;
+}
+void join_early_alloc(qh_state_s *h) {
+  if (h->alt_thread.joinable()) h->alt_thread.join();
+}
+// qh_create: large owning handles ask for their second buffer at once, on a helper thread (QH_PREALLOC=0: never)
+thread_local bool g_no_early_alloc = false;     // (the per-thread scratch handles of the literal drop-in never use a second buffer)
+void start_early_alloc(qh_state_s *h) {
+  const size_t bytes = (size_t)h->amp_bytes() << h->nloc;
+  if (g_no_early_alloc || bytes < (1ull << 30) || env_int("QH_PREALLOC", 1) == 0 || !relayout_eligible(h) || !second_buffer_fits(h, bytes)) return;
+  const int device = h->device;
+  h->alt_thread = std::thread([h, bytes, device] {
+    void *p = nullptr;
+    if (hipSetDevice(device) == hipSuccess && alloc_state_buffer(&p, bytes) == hipSuccess) h->alt_early = p;
+    else (void)hipGetLastError();
+  });
+}
+bool alloc_second_buffer(qh_state_s *h) {
+  if (h->d_alt) return true;
+  join_early_alloc(h);
+  if (h->alt_early) {
+    h->d_alt = h->alt_early;
+    h->alt_early = nullptr;
+    return true;
+  }
+  const size_t bytes = (size_t)h->amp_bytes() << h->nloc;
+  if (second_buffer_fits(h, bytes) && alloc_state_buffer(&h->d_alt, bytes) == hipSuccess)
     return true;
   (void)hipGetLastError();
   h->d_alt = nullptr;
@@ -529,6 +548,8 @@ int set_relayout(qh_state_s *h, bool on, int *actual = nullptr) {
     rc = flush_impl(h);
     if (rc == QH_OK) rc = canonicalize(h);
     if (rc) return rc;
+    join_early_alloc(h);
+    if (h->alt_early) { (void)hipFree(h->alt_early); h->alt_early = nullptr; }
     if (h->d_alt) {
       HIP_TRY(hipStreamSynchronize(h->stream));
       (void)hipFree(h->d_alt);
@@ -628,7 +649,7 @@ int select_device(int device) {
 extern "C" {
 
 const char *qh_last_error(void) { return g_err.c_str(); }
-int qh_version(void) { return 100; }
+int qh_version(void) { return 105; }   // 100 + round: bumped whenever plans, exchange geometry or the C-ABI change
 
 int qh_device_count(int *count) {
   if (!count) return fail(QH_ERR_ARG, "null");
@@ -668,6 +689,7 @@ int qh_create(int nbits, int bit_width, int device, qh_handle *out) {
     qh_destroy(h);
     return rc;
   }
+  start_early_alloc(h);
   *out = h;
   return QH_OK;
 }
@@ -752,6 +774,8 @@ int qh_destroy(qh_handle h) {
   if (h->dry) (void)qh_comm_destroy(h);
   if (!h->dry) {
     (void)hipSetDevice(h->device);
+    join_early_alloc(h);
+    if (h->alt_early) (void)hipFree(h->alt_early);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     (void)qh_comm_destroy(h);
     qh::free_sweep_buffers(&h->sweep);
@@ -952,9 +976,12 @@ int qh_upload(qh_handle h, const void *host, uint64_t offset, uint64_t count) {
   if (!h || !host || h->dry) return fail(QH_ERR_ARG, "null/dry");
   if (offset + count > (1ull << h->nloc)) return fail(QH_ERR_ARG, "upload range out of bounds");
   HIP_TRY(hipSetDevice(h->device));
-  if (offset == 0 && count == (1ull << h->nloc) && h->poisoned) {   // the whole shard is replaced: a fresh start
+  if (offset == 0 && count == (1ull << h->nloc)) {
+    // the whole shard is replaced: a fresh start -- nothing queued is worth running, a failed flush is forgotten, and a
+    // plain handle goes back to canonical order without moving a byte (like the initialisations)
     h->queue.clear();
     h->poisoned = false;
+    reset_layout_for_init(h);
   }
   int rc = flush_impl(h);
   if (rc == QH_OK) rc = canonicalize(h);
@@ -1309,7 +1336,12 @@ int qh_plan_export(qh_handle h, void *buf, uint64_t cap, uint64_t *needed) {
     put_bytes(hdr, sizeof hdr);
     put_bytes(sp.dest_pos, 64);
     {
-      int64_t st[5] = {sp.lanehi_store[0], sp.lanehi_store[1], sp.lanehi_store[2], sp.wavepos_store[0], sp.wavepos_store[1]};
+      // lanes: the index bit on lane bit i at load time, at store time, and the position 0..5 a relayout store sends it to;
+      // then the wave bits at store time
+      int64_t st[20] = {0};
+      for (int i = 0; i < 6; ++i) { st[i] = sp.seat[i]; st[6 + i] = sp.seat_store[i]; st[12 + i] = sp.seat_dest[i]; }
+      st[18] = sp.wavepos_store[0];
+      st[19] = sp.wavepos_store[1];
       put_bytes(st, sizeof st);
       // what the kernel is handed for a relayout store: register / wave bit destinations and the runs of
       // unit-index bits (count, then 8 x mask, 8 x shift)
@@ -1426,8 +1458,10 @@ int verify_geometry(qh_state_s *h, uint64_t sig) {
       if (theirs[k] != sig)
         return fail(QH_ERR_COMM, "exchange geometry differs between rank %d (%016llx) and rank %d (%016llx): the ranks "
                     "planned different sweeps or layouts", c->rank, (unsigned long long)sig, peers[k], (unsigned long long)theirs[k]);
+    c->stats.geometry_checks++;
     return QH_OK;
   }
+  if (!c->nccl) return fail(QH_ERR_COMM, "no RCCL communicator on this handle (never set up, or aborted by the watchdog)");
   // RCCL: every geometry this communicator has not compared yet (QH_EXCHANGE_VERIFY=1: every exchange, =0: never).
   // The all-reduce runs on the EXCHANGE stream -- it does not wait for the sweeps queued on the compute stream --
   // and the host waits for it: once per distinct geometry (a loop over one circuit cycles through a few layouts).
@@ -1451,18 +1485,20 @@ int verify_geometry(qh_state_s *h, uint64_t sig) {
                 "(QH_* environment) or builds", c->rank, (unsigned long long)sig, (unsigned)w[0], (unsigned)w[1], (unsigned)-w[2], (unsigned)-w[3]);
   if (c->verified.size() >= 256) c->verified.erase(c->verified.begin());
   c->verified.push_back(sig);
+  c->stats.geometry_checks++;
   return QH_OK;
 }
 
 // What must be equal on every rank besides the geometry itself: the planner's switches and the build.
 uint64_t env_build_hash() {
   std::string s = qh::planner_env_signature();
-  for (const char *n : {"QH_EXCHANGE_SLAB_BITS", "QH_EXCHANGE_PACK", "QH_RELAYOUT", "QH_LTAB_LDS", "QH_SWEEP_BLOCK_WAVES", "QH_SUPERS_PER_BLOCK"}) {
-    const char *e = getenv(n);
-    s += e ? e : "-";
-    s += ';';
-  }
-  s += __DATE__ " " __TIME__;
+  // (the EFFECTIVE values: an unset switch and one set to its default are the same plan)
+  s += std::to_string(env_int("QH_EXCHANGE_SLAB_BITS", 3)) + ";" + std::to_string(env_int("QH_EXCHANGE_PACK", -1)) + ";" +
+       std::to_string(env_int("QH_RELAYOUT", 1) != 0) + ";";
+  // the build: the library's version and the layouts the planner and the kernels share -- NOT the time of compilation (two
+  // nodes that build the same sources in-tree must be able to exchange)
+  s += "v" + std::to_string(qh_version()) + ":" + std::to_string(sizeof(qh::SweepArgs)) + ":" + std::to_string(sizeof(qh::SweepOp)) +
+       ":" + std::to_string(sizeof(qh::SweepPlan)) + ":" + std::to_string(sizeof(qh_xgeom));
   uint64_t hsh = 0xcbf29ce484222325ull;
   for (unsigned char ch : s) { hsh ^= ch; hsh *= 0x100000001b3ull; }
   return hsh;
@@ -1756,6 +1792,13 @@ int qh_comm_init(qh_handle h, int nranks, int rank, const void *id) {
     (void)qh_comm_destroy(h);
     return fail(QH_ERR_COMM, "ncclCommInitRank(%d of %d): %s", rank, nranks, qh::rccl().GetErrorString(r));
   }
+  int cnt = 0, ur = -1;      // what the communicator itself says (reported in qh_xstats: bench.py prints it)
+  if (qh::rccl().CommCount(h->comm->nccl, &cnt) == ncclSuccess) h->comm->stats.comm_ranks = (uint32_t)cnt;
+  if (qh::rccl().CommUserRank(h->comm->nccl, &ur) == ncclSuccess) h->comm->stats.comm_rank = (uint32_t)ur;
+  if (cnt != nranks || ur != rank) {
+    (void)qh_comm_destroy(h);
+    return fail(QH_ERR_COMM, "the RCCL communicator reports rank %d of %d, asked for %d of %d", ur, cnt, rank, nranks);
+  }
   return QH_OK;
 }
 
@@ -1765,6 +1808,8 @@ int qh_comm_init_custom(qh_handle h, int nranks, int rank, qh_round_fn fn, void 
   if (rc) return rc;
   h->comm->custom = fn;
   h->comm->custom_user = user;
+  h->comm->stats.comm_ranks = (uint32_t)nranks;
+  h->comm->stats.comm_rank = (uint32_t)rank;
   return QH_OK;
 }
 
@@ -1915,7 +1960,9 @@ static int host_handle(int nbits, int bw, qh_handle *out) {
   if (g_host.slot[1]) qh_destroy(g_host.slot[1]);
   g_host.slot[1] = g_host.slot[0];
   g_host.slot[0] = nullptr;
+  g_no_early_alloc = true;
   int rc = qh_create(nbits, bw, 0, &g_host.slot[0]);
+  g_no_early_alloc = false;
   if (rc) return rc;
   g_host.slot[0]->relayout = 0;   // one gate per call: nothing to gain from a second buffer
   *out = g_host.slot[0];

@@ -75,6 +75,9 @@ struct RcclApi {
   decltype(&ncclGroupEnd) GroupEnd = nullptr;
   decltype(&ncclAllReduce) AllReduce = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclCommAbort) CommAbort = nullptr;
+  decltype(&ncclCommCount) CommCount = nullptr;
+  decltype(&ncclCommUserRank) CommUserRank = nullptr;
   std::string where;
 
   bool load(std::string *err) {
@@ -109,6 +112,9 @@ struct RcclApi {
     GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
     AllReduce = (decltype(AllReduce))sym("ncclAllReduce");
     GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+    CommAbort = (decltype(CommAbort))sym("ncclCommAbort");
+    CommCount = (decltype(CommCount))sym("ncclCommCount");
+    CommUserRank = (decltype(CommUserRank))sym("ncclCommUserRank");
     if (!ok) { lib = nullptr; return false; }
     return true;
   }

@@ -163,6 +163,15 @@ struct SweepPlan {
   int lane_low = kLaneLow;         // lane bits below this are the index bits of the same number
   int lanehi[kLaneHi] = {3, 4, 5}; // ascending positions of the 6 - lane_low movable lane bits ({lane_low..5} = contiguous runs)
   int nlanehi() const { return kLaneBits - lane_low; }
+  // SEATS: which index bit each of the six lane bits holds.  The lane-resident bits of a tile are the line bits
+  // 0..lane_low-1 plus lanehi[]; by default lane bit i holds the i-th of them.  Which LANE holds which amplitude of a
+  // 128-byte line is free for the memory system (profiles/r04/lanemap_membench.txt: < 1-2.5 %), but not for the op
+  // stream: a butterfly on lane bit 4 / 5 runs as a v_permlane swap + register butterfly (72 + 64 VALU instructions, and
+  // the bit then LIVES in a register), on lane bits 0, 1, 3 as 206 instructions of DPP moves, on lane bit 2 as 334.  So
+  // op-heavy sweeps seat their busiest lane-resident bits on lane bits 5 and 4 and the idlest on lane bit 2 (build_sweep).
+  int seat[kLaneBits] = {0, 1, 2, 3, 4, 5};         // index bit held by lane bit i when the tile is loaded
+  int seat_store[kLaneBits] = {0, 1, 2, 3, 4, 5};   // ... when it is stored (lane <-> register exchanges may stay: relayout)
+  int seat_dest[kLaneBits] = {0, 1, 2, 3, 4, 5};    // relayout store: position 0..5 the bit on lane bit i goes to
   bool contiguous() const {
     for (int k = 0; k < nlanehi(); ++k) if (lanehi[k] != lane_low + k) return false;
     return true;
@@ -177,8 +186,7 @@ struct SweepPlan {
   // new position of the index bit at position p (local bits only).  See Planner::relayout().
   bool relayout = false;
   uint8_t dest_pos[64] = {0};
-  int lanehi_store[kLaneHi] = {3, 4, 5};   // index bits the movable lane bits / wave bits hold when the
-  int wavepos_store[kMaxWaveBits] = {0};   // tile is stored (only a relayout sweep may leave them exchanged)
+  int wavepos_store[kMaxWaveBits] = {0};   // index bits the wave bits hold when the tile is stored (lanes: seat_store)
   int reg_dest[kMaxRegBits] = {6, 7, 8, 9, 10, 11};  // relayout: where register bit k / wave bit j go (positions 6.. of the
   int wave_dest[kMaxWaveBits] = {11, 12};        // contiguous block, in ascending order of the index bits they hold)
   std::vector<SweepOp> ops;
@@ -218,8 +226,8 @@ inline uint64_t gate_alg_bytes(const GateRec &r, int nloc, uint64_t amp_bytes) {
 // those bits.  P is handed to the kernel as runs of bits that move together: dst |= shift(w & mask).
 constexpr int kMaxUnitSegs = 8;
 inline int unit_segments(const SweepPlan &sp, int nloc, uint64_t *masks, int *shifts) {
-  uint64_t tile = (1ull << sp.lane_low) - 1;
-  for (int k = 0; k < sp.nlanehi(); ++k) tile |= 1ull << sp.lanehi_store[k];
+  uint64_t tile = 0;
+  for (int i = 0; i < kLaneBits; ++i) tile |= 1ull << sp.seat_store[i];
   for (int k = 0; k < sp.rb; ++k) tile |= 1ull << sp.regpos_store[k];
   for (int k = 0; k < sp.nwave; ++k) tile |= 1ull << sp.wavepos_store[k];
   const int tilebits = popc(tile);
@@ -413,7 +421,6 @@ class Planner {
     const int cap = lane_hi_ + rb_cap_ + max_wave_;
     if ((size_t)popc(movable) > K * (size_t)cap) return false;       // not even room to visit every qubit once
     uint64_t rng = 0x9e3779b97f4a7c15ull;
-    if (const char *e = getenv("QH_PLAN_SEARCH_SEED")) rng ^= strtoull(e, nullptr, 10) * 0xd1342543de82ef95ull;   // (experiments)
     auto rnd = [&](uint32_t n) { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return (uint32_t)((rng >> 11) % n); };
     auto pick_bit = [&](uint64_t m) { int k = (int)rnd((uint32_t)popc(m)); while (k--) m &= m - 1; return __builtin_ctzll(m); };
     std::vector<uint64_t> start, cur, best_tiles;
@@ -435,7 +442,7 @@ class Planner {
     // 0.3 M visits); the first that empties the queue wins.  Circuits without a solution mostly show it at once (the
     // 34-qubit Grover iteration, one supremacy instance in twelve: no move ever lowers the left-over): two attempts in
     // a row without any progress end the search.
-    static const int attempts = std::max(1, env_int("QH_PLAN_SEARCH_ATTEMPTS", 8));
+    constexpr int attempts = 8;
     const uint64_t attempt_budget = std::max<uint64_t>(step_budget / attempts, 300000);
     size_t best = ~(size_t)0;
     const uint64_t rng0 = rng;
@@ -493,9 +500,7 @@ class Planner {
         }
       }
       fruitless = abest == start_left ? fruitless + 1 : 0;
-      if (getenv("QH_PLAN_SEARCH_DEBUG")) fprintf(stderr, "[qh search attempt %llu: left=%zu %s visits=%llu]\n", (unsigned long long)attempt, abest, walks_without_gain >= 4 ? "stuck" : (abest ? "budget" : "solved"), (unsigned long long)steps);
     }
-    if (getenv("QH_PLAN_SEARCH_DEBUG")) fprintf(stderr, "[qh search K=%zu left=%zu visits=%llu]\n", K, best, (unsigned long long)steps);
     if (best > 0) return false;
     tiles_out->clear();
     for (uint64_t t : best_tiles) {
@@ -515,13 +520,14 @@ class Planner {
     prepare(queue, &pending, &alg, &out.noop_gates);
     const uint64_t lm = (1ull << nloc_) - 1;
     std::vector<int> first_tile;
+    keep_line_bits_ = !tiles_.empty();
     while (!pending.empty()) {
       std::vector<GateRec> rest;
       std::vector<uint64_t> rest_alg;
       std::vector<uint32_t> rest_w;
       std::vector<int> forced;
       const std::vector<int> *fs = nullptr;
-      if (out.sweeps.size() < tiles_.size()) {          // tiles chosen for the whole flush (QH_FORCE_TILES / the tile search),
+      if (out.sweeps.size() < tiles_.size()) {          // tiles chosen for the whole flush (the tile search),
         for (int b : tiles_[out.sweeps.size()])         // in the bit numbering the flush started with
           if (b >= lane_low_ && b < nloc_) forced.push_back(out.final_pos[b]);
         fs = &forced;
@@ -579,38 +585,29 @@ class Planner {
   bool relayout_;      // sweeps may store into the second buffer with the tile bits moved to the low positions
   bool keep_ghosts_;   // sharded handle: gates that do nothing on this rank stay in the list (GateRec::ghost)
   bool butterflies_ = env_flag("QH_BFLY", true);        // unit-entry butterfly ops (emit_ops_with)
-  size_t dense_weight_ = env_int("QH_PLAN_DENSE_W", 1);  // score of a dense gate when choosing tile bits (diagonal = 1)
+  static constexpr size_t dense_weight_ = 1;             // score of a dense gate when choosing tile bits (diagonal = 1)
   // wave bits per tile (see plan_best): QH_WAVE_BITS pins it
   int max_wave_ = std::max(0, std::min(kMaxWaveBits, env_int("QH_WAVE_BITS", 1)));
   bool propagate_x_ = env_flag("QH_PROPAGATE_X", true);   // see propagate_x
-  bool store_swapped_ = env_flag("QH_STORE_SWAPPED", true);
-  bool lanes_by_count_ = env_flag("QH_LANES_BY_COUNT", true);
-  bool lanes_high_ = env_flag("QH_LANES_HIGH", true);
-  int min_table_terms_ = env_int("QH_MIN_TABLE_TERMS", 2);
-  bool bitfac_ = env_flag("QH_BITFAC", true);            // DG_BITFAC groups (fuse_bit_factors)
-  bool fold_sink_ = env_flag("QH_FOLD_SINK", true);      // the butterflies' scalars join a phase factor (emit_ops_with)
+  // Settled by measurement in rounds 2-4 and no longer switchable (profiles/r02..r04): in-place sweeps of
+  // contiguous tiles store their wave exchanges un-undone; the least-used tile bits take the lane roles in op-heavy sweeps;
+  // lane bits above the 2-MiB page come from the top; a chunk table needs two terms; controlled-phase ladders are factor
+  // trees (DG_BITFAC); the butterflies' scalars ride on a phase factor; a relayout store puts the next sweep's targets
+  // above the tile; the gates of a sweep are reordered for fewer layout exchanges; a lane <-> register exchange precedes
+  // the phases of its gate.
+  static constexpr bool store_swapped_ = true, lanes_by_count_ = true, lanes_high_ = true, bitfac_ = true, fold_sink_ = true;
+  static constexpr int min_table_terms_ = 2;
   bool fold_pending_ = false;                            // ... still to be placed in the sweep being emitted
+  bool keep_line_bits_ = false;                          // the flush runs on pre-chosen tiles: see emit_ops_with (relayout stores)
   double fold_re_ = 1, fold_im_ = 0;
   int lane_valu_ = env_int("QH_LANE_VALU", 1);          // 0 never, 1 by cost model (choose_lane_paths), 2 always (tests)
   bool defer_diag_ = env_flag("QH_DEFER_DIAG", true);   // see build_sweep
-  bool lookahead_ = env_flag("QH_RELAYOUT_AHEAD", true); // see finish_relayout
-  bool reorder_ = env_flag("QH_REORDER", true);                    // see reorder_for_fewer_swaps
+  static constexpr bool lookahead_ = true, reorder_ = true, lswap_early_ = true;   // see finish_relayout, reorder_for_fewer_swaps, emit_ops_with
   bool rot_fuse_ = env_flag("QH_ROT_FUSE", true);                 // a pi/4-type phase on a butterfly's target rides in the butterfly (emit_ops_with)
-  bool lswap_early_ = env_flag("QH_LSWAP_EARLY", true);            // lane <-> register exchange before the phases of its gate (emit_ops_with)
+  int seats_ = env_int("QH_SEATS", 1);                             // op-heavy sweeps seat their lane-resident bits by cost (choose_seats)
   std::vector<uint64_t> alg_override_;
   std::vector<uint32_t> weight_;  // reference gate applications each pending record stands for
-  std::vector<std::vector<int>> tiles_ = parse_tiles(getenv("QH_FORCE_TILES"));   // "3,6,7;12,13" = tile bits of sweep 0; sweep 1 (experiments)
-  static std::vector<std::vector<int>> parse_tiles(const char *s) {
-    std::vector<std::vector<int>> out;
-    if (!s || !*s) return out;
-    out.emplace_back();
-    for (const char *p = s; *p;) {
-      if (*p == ';') { out.emplace_back(); ++p; }
-      else if (*p == ',' || *p == ' ') ++p;
-      else { char *e; out.back().push_back((int)strtol(p, &e, 10)); if (e == p) break; p = e; }
-    }
-    return out;
-  }
+  std::vector<std::vector<int>> tiles_;   // tile bits of sweep 0, sweep 1, ... chosen for the whole flush (the tile search: set_tiles)
 
   static bool near(double a, double b) { return std::fabs(a - b) <= 4e-15; }
   static bool same_gate(const double a[8], const double b[8]) {
@@ -1097,12 +1094,37 @@ class Planner {
     for (int k = 0; k < sp.rb; ++k) sp.regpos[k] = regs[k];
     sp.lane_low = lane_low_;
     for (int k = 0; k < kLaneHi; ++k) sp.lanehi[k] = k < lane_hi_ ? lanehi[k] : -1;
+    for (int i = 0; i < kLaneBits; ++i) sp.seat[i] = i < lane_low_ ? i : lanehi[i - lane_low_];
+    choose_seats(taken, &sp);
     sp.nwave = nwv;
     for (int k = 0; k < nwv; ++k) sp.wavepos[k] = waves[k];
     sp.ntiles = 1ull << (nloc_ - kLaneBits - sp.rb - popc(common));
     sp.swept_bytes = (sp.ntiles << (kLaneBits + sp.rb)) * amp_bytes_ * 2;
     emit_ops(taken, &sp);
     return sp;
+  }
+
+  // Seats of the six lane-resident bits (SweepPlan::seat) of an op-heavy sweep, by what a dense gate costs there: the two
+  // bits with the most dense gates take lane bits 5 and 4 (v_permlane swap, then register butterflies for as long as the
+  // bit stays in a register), the one with the fewest lane bit 2 (two DPP moves per dword), the rest lane bits 3, 0, 1.
+  // Sweeps with few dense gates keep the plain map (index bit i on lane bit i: the best one for the memory system).
+  // Ghost gates count like live ones (the seats shape the exchange geometry's layouts: rank-invariant).
+  void choose_seats(const std::vector<const GateRec *> &taken, SweepPlan *sp) const {
+    if (!seats_ || amp_bytes_ != 16) return;
+    int cnt[64] = {0}, ndense = 0;
+    for (const GateRec *r : taken)
+      if (!plan_diag(*r) && r->tgt >= 0) { cnt[r->tgt]++; ndense++; }
+    if (ndense < 16 && seats_ < 2) return;           // (QH_SEATS=2: every sweep, whatever it saves -- tests)
+    static const int kSeatCost[kLaneBits] = {206, 206, 334, 206, 100, 100};   // (4, 5: exchange shared by the gates that follow)
+    static const int kSeatOrder[kLaneBits] = {5, 4, 3, 0, 1, 2};              // busiest bit first
+    int bits[kLaneBits];
+    for (int i = 0; i < kLaneBits; ++i) bits[i] = sp->seat[i];
+    std::stable_sort(bits, bits + kLaneBits, [&](int a, int b) { return cnt[a] > cnt[b]; });
+    long before = 0, after = 0;
+    for (int i = 0; i < kLaneBits; ++i) before += (long)cnt[sp->seat[i]] * kSeatCost[i];
+    for (int i = 0; i < kLaneBits; ++i) after += (long)cnt[bits[i]] * kSeatCost[kSeatOrder[i]];
+    if (before - after < 128 && seats_ < 2) return;
+    for (int i = 0; i < kLaneBits; ++i) sp->seat[kSeatOrder[i]] = bits[i];
   }
 
   int reg_index(const SweepPlan &sp, int pos) const {
@@ -1117,8 +1139,7 @@ class Planner {
 
   // lane-bit index (0..5) of a physical index bit, -1 if it is not a lane bit of this tile
   static int lane_index(const SweepPlan &sp, int pos) {
-    if (pos >= 0 && pos < sp.lane_low) return pos;
-    for (int k = 0; k < sp.nlanehi(); ++k) if (sp.lanehi[k] == pos) return sp.lane_low + k;
+    for (int i = 0; i < kLaneBits; ++i) if (sp.seat[i] == pos) return i;
     return -1;
   }
 
@@ -1156,7 +1177,7 @@ class Planner {
   // tiles, and under this load the clock drops to 1.7-2.1 GHz.  Measured inside the kernel (s_memtime per op,
   // tools/probes/prof_island.sh): a bpermute butterfly keeps its wave for 3 200-7 700 cycles when the other
   // eleven waves of the CU queue at the same pipe, a DPP one for 1 300-3 000, swap + register butterfly for
-  // 1 800-2 500.  So a sweep whose LDS pipe would be busy for more than QH_LDS_FLOOR cycles per tile
+  // 1 800-2 500.  So a sweep whose LDS pipe would be busy for more than 2 500 cycles per tile
   // (default 2 500: a third of the HBM time of a tile -- three lane butterflies and a wave exchange) moves
   // ALL its lane butterflies to the VALU; lighter sweeps keep the LDS path (30-qubit QFT first sweep
   // 6.7 -> 6.35 ms, its other two 6.05 -> 5.87; supremacy 47.9 -> 47.1; QFT-33 159 -> 153).
@@ -1168,7 +1189,7 @@ class Planner {
       if (o.kind == OP_WSWAP) lds += 256 * dw;      // 16 ds_write_b128 + 16 ds_read_b128, 8 cycles each
       else if (o.kind == OP_DENSE_LANE) lds += kLds;
     }
-    const double floor_cycles = env_int("QH_LDS_FLOOR", 2500);   // (read at every flush, like the other planner switches)
+    const double floor_cycles = 2500;
     LaneChoice ch;
     // (Round 4 tried the middle ground -- leave butterflies on the otherwise idle LDS pipe up to a budget of pipe cycles
     // per tile, cheapest VALU alternative moved first -- on the premise that op-heavy sweeps are bound by VALU issue:
@@ -1208,7 +1229,8 @@ class Planner {
         if ((dense[i] & all[j]) || (dense[j] & all[i])) { succ[i].push_back((uint32_t)j); ndep[j]++; }
     uint64_t regs = 0, cheap = (1ull << sp.lane_low) - 1;        // where a dense gate needs no exchange
     for (int k = 0; k < sp.rb; ++k) regs |= 1ull << sp.regpos[k];
-    for (int k = 0; k < sp.nlanehi(); ++k) if (sp.lane_low + k < 4) cheap |= 1ull << sp.lanehi[k];   // lane bit 3: DPP, no exchange
+    cheap = 0;
+    for (int i = 0; i < 4; ++i) cheap |= 1ull << sp.seat[i];                                          // lane bits 0..3: DPP, no exchange
     std::vector<uint8_t> done(n, 0);
     std::vector<const GateRec *> out;
     out.reserve(n);
@@ -1315,6 +1337,7 @@ class Planner {
     geom.fixed_ones = sp->fixed_ones;
     memcpy(geom.regpos, sp->regpos, sizeof geom.regpos);
     memcpy(geom.lanehi, sp->lanehi, sizeof geom.lanehi);
+    memcpy(geom.seat, sp->seat, sizeof geom.seat);
     geom.lane_low = sp->lane_low;
     geom.nwave = sp->nwave;
     memcpy(geom.wavepos, sp->wavepos, sizeof geom.wavepos);
@@ -1328,10 +1351,10 @@ class Planner {
       op.cm_reg = (uint32_t)r;
       // the kernel moves the thread's own bit from the lane's index position to the register's (its thread
       // index keeps describing the amplitudes it holds: lane / outside controls and OP_WSWAP rely on it)
-      op.n_groups = (uint32_t)geom.lanehi[li - geom.lane_low];
-      op.cm_thread = (1ull << geom.lanehi[li - geom.lane_low]) | (1ull << geom.regpos[r]);
+      op.n_groups = (uint32_t)geom.seat[li];
+      op.cm_thread = (1ull << geom.seat[li]) | (1ull << geom.regpos[r]);
       sp->ops.push_back(op);
-      std::swap(geom.lanehi[li - geom.lane_low], geom.regpos[r]);
+      std::swap(geom.seat[li], geom.regpos[r]);
     };
     auto wswap = [&](int wi, int r) {
       SweepOp op{};
@@ -1567,13 +1590,27 @@ class Planner {
     // now: neither kind of exchange is undone (see relayout()).
     if (want_relayout(*sp, !swaps.empty())) {
       sp->relayout = true;      // (dest_pos: plan() -> finish_relayout, once the next sweep's targets are known)
+      // Tiles chosen for the whole flush (the tile search) count on the line bits being part of every
+      // tile: a line bit that an exchange has left in a register (or, through a register, in the wave id) comes back to
+      // the lanes before the store, so that positions 0..lane_low-1 hold the same qubits in the next sweep.  Without such
+      // tiles the next sweep simply selects its tile around whatever sits there.
+      if (keep_line_bits_)
+        for (int b = 0; b < geom.lane_low; ++b) {
+          if (lane_index(geom, b) >= 0) continue;
+          const int wi = wave_index(geom, b);
+          if (wi >= 0) wswap(wi, victim_reg());
+          const int r = reg_index(geom, b);
+          int li = -1;
+          for (int sidx = kLaneBits - 1; sidx >= 4; --sidx) if (geom.seat[sidx] >= geom.lane_low) li = sidx;
+          if (r >= 0 && li >= 0) lswap(li, r);
+        }
     } else if (store_swapped_ && sp->contiguous()) {
       if (!undo_lane_swaps()) restore_layout();
     } else {
       restore_layout();
     }
     memcpy(sp->regpos_store, geom.regpos, sizeof geom.regpos);
-    memcpy(sp->lanehi_store, geom.lanehi, sizeof geom.lanehi);
+    memcpy(sp->seat_store, geom.seat, sizeof geom.seat);
     memcpy(sp->wavepos_store, geom.wavepos, sizeof geom.wavepos);
     // lane tables go to the front of `tables` (one contiguous block: the kernel copies it to LDS)
     const uint32_t nlt = (uint32_t)(sp->ltabs.size() / 2);
@@ -1609,15 +1646,32 @@ class Planner {
   // N3 "qubit remapping to keep hot targets in low bits": a gather from lines 64 KiB - 16 MiB apart
   // runs at 5.8 ms per 2 x 16 GiB, from lines >= 32 MiB apart at 6.5-6.9); the rest above, order kept.
   void finish_relayout(SweepPlan *sp, const std::vector<int> &ahead) const {
-    uint64_t placed = (1ull << sp->lane_low) - 1;
-    for (int p = 0; p < sp->lane_low; ++p) sp->dest_pos[p] = (uint8_t)p;
-    int next = sp->lane_low;
+    // the six bits on the lanes at store time take positions 0..5: a line bit keeps its own position, the others fill
+    // the free ones in ascending order of the index bits they hold -- whatever their seats were (the layout a sweep
+    // leaves, hence the next sweep's gather pattern, does not depend on how this one seated its lanes)
+    uint64_t placed = 0, used = 0;
+    int order[kLaneBits];
+    for (int i = 0; i < kLaneBits; ++i) order[i] = sp->seat_store[i];
+    std::sort(order, order + kLaneBits);
+    for (int i = 0; i < kLaneBits; ++i) {
+      const int b = order[i];
+      if (b < sp->lane_low) { sp->dest_pos[b] = (uint8_t)b; placed |= 1ull << b; used |= 1ull << b; }
+    }
+    for (int i = 0; i < kLaneBits; ++i) {
+      const int b = order[i];
+      if ((placed >> b) & 1ull) continue;
+      const int d = __builtin_ctzll(~used);
+      sp->dest_pos[b] = (uint8_t)d;
+      used |= 1ull << d;
+      placed |= 1ull << b;
+    }
+    for (int i = 0; i < kLaneBits; ++i) sp->seat_dest[i] = sp->dest_pos[sp->seat_store[i]];
+    int next = kLaneBits;
     auto put = [&](int p) {
       if (p < 0 || p >= nloc_ || ((placed >> p) & 1ull)) return;
       sp->dest_pos[p] = (uint8_t)next++;
       placed |= 1ull << p;
     };
-    for (int k = 0; k < sp->nlanehi(); ++k) put(sp->lanehi_store[k]);
     // register and wave bits share the positions above the lanes, sorted by the index bits they hold:
     // the block keeps its bits in ascending order (but for the lanes), so the phase tables of later
     // sweeps keep finding their eight-bit windows filled
@@ -1670,6 +1724,9 @@ class Planner {
     // load per 8 index bits at run time); the rest stay loop terms
     auto attach_outside = [&](DGroup &g, PGroup &pg) {
       std::vector<OTerm> loop_terms = pg.multi;
+      // (a line bit that an exchange has carried into the wave id is an outside bit below the table windows: a loop term)
+      for (size_t k = pg.single.size(); k-- > 0;)
+        if (pg.single[k].mask < (1ull << sp->lane_low)) { loop_terms.push_back(pg.single[k]); pg.single.erase(pg.single.begin() + (long)k); }
       for (int shift = sp->lane_low; shift < 64 && !pg.single.empty(); shift += 8) {
         const uint64_t cmask = (shift + 8 >= 64) ? (~0ull << shift) : (((1ull << 8) - 1) << shift);
         std::vector<OTerm> in;
@@ -1853,68 +1910,53 @@ inline bool plan_has_far_tile(const PlanResult &pr) {
 inline PlanResult plan_best(const std::vector<GateRec> &queue, int nloc, uint64_t shard, int bw, int max_rb,
                             bool split_lanes, bool allow_relayout = false, bool keep_ghosts = false) {
   if (getenv("QH_WAVE_BITS")) return Planner(nloc, shard, bw, max_rb, split_lanes, -1, allow_relayout, keep_ghosts).plan(queue);
-  if (!env_flag("QH_PLAN_EXHAUSTIVE", false)) {
-    // the same choice from the tile selections alone (Planner::skeleton), then ONE full plan: a third of the
-    // planning time of three full plans (30-qubit QFT: 1.9 -> 0.9 ms)
-    int best_wb = 1;
-    size_t best_n = 0;
-    bool have = false, best_far = false;
-    for (int wb : {1, 2, 0}) {
-      size_t n = 0;
-      bool far = false;
-      Planner(nloc, shard, bw, max_rb, split_lanes, wb, allow_relayout, keep_ghosts).skeleton(queue, &n, &far);
-      if (!have || (best_far && !far) || (best_far == far && n < best_n)) {
-        best_wb = wb;
-        best_n = n;
-        best_far = far;
-        have = true;
-      }
-      if (best_n <= 1 && !best_far) break;
-    }
-    Planner chosen(nloc, shard, bw, max_rb, split_lanes, best_wb, allow_relayout, keep_ghosts);
-    // one sweep less?  Worth a search only where a sweep costs about what the search does: budget = the gate visits
-    // that fit into ~1.6 sweep times (2 x state bytes at 5.5 TB/s, ~2.5 ns per gate visit: 4 M visits = ~10 ms of host
-    // time for a 16-GiB state, hidden behind the GPU whenever circuits are submitted back to back, paid once per
-    // circuit with the plan cache on; eight supremacy-30 instances: 5 6 6 6 7 7 6 6 sweeps greedy, 4 6 5 5 6 6 5 5 with
-    // the search).  QH_PLAN_SEARCH=0 switches it off, QH_PLAN_SEARCH_STEPS pins the budget.
-    uint64_t dense_bits = 0;
-    for (const GateRec &q : queue) if (q.tgt >= 0 && q.tgt < nloc && !plan_diag(q.g, q.tgt)) dense_bits |= 1ull << q.tgt;
-    const int lane_low = bw == 128 ? 3 : 4;
-    const int cap = (kLaneBits - lane_low) + std::min({max_rb, max_reg_bits(bw), nloc - kLaneBits}) + best_wb;
-    const bool room = best_n >= 3 && popc(dense_bits >> lane_low) <= (int)(best_n - 1) * cap;   // every qubit visited at least once
-    if (room && env_flag("QH_PLAN_SEARCH", true) && !getenv("QH_FORCE_TILES")) {
-      const double sweep_us = 2.0 * (double)(bw == 128 ? 16 : 8) * (double)(1ull << nloc) / 5.5e6;
-      uint64_t budget = std::min<uint64_t>((uint64_t)(sweep_us * 650.0), 8000000);      // ~1.6 sweep times of host work, at most ~20 ms
-      if (const char *e = getenv("QH_PLAN_SEARCH_STEPS")) budget = strtoull(e, nullptr, 10);
-      if (budget >= 20000) {
-        std::vector<uint64_t> greedy;
-        size_t n = 0;
-        bool far = false;
-        Planner(nloc, shard, bw, max_rb, split_lanes, best_wb, allow_relayout, keep_ghosts).skeleton(queue, &n, &far, &greedy);
-        std::vector<std::vector<int>> tiles;
-        if (Planner(nloc, shard, bw, max_rb, split_lanes, best_wb, allow_relayout, keep_ghosts).search_tiles(queue, greedy, budget, &tiles)) {
-          Planner forced(nloc, shard, bw, max_rb, split_lanes, best_wb, allow_relayout, keep_ghosts);
-          forced.set_tiles(tiles);
-          PlanResult pr = forced.plan(queue);
-          if (pr.sweeps.size() < best_n && !plan_has_far_tile(pr)) return pr;     // (the model ignores relabelling: check)
-        }
-      }
-    }
-    return chosen.plan(queue);
-  }
-  PlanResult best;
+  // the same choice from the tile selections alone (Planner::skeleton), then ONE full plan: a third of the
+  // planning time of three full plans (30-qubit QFT: 1.9 -> 0.9 ms)
+  int best_wb = 1;
+  size_t best_n = 0;
   bool have = false, best_far = false;
   for (int wb : {1, 2, 0}) {
-    PlanResult pr = Planner(nloc, shard, bw, max_rb, split_lanes, wb, allow_relayout, keep_ghosts).plan(queue);
-    const bool far = plan_has_far_tile(pr);
-    if (!have || (best_far && !far) || (best_far == far && pr.sweeps.size() < best.sweeps.size())) {
-      best = std::move(pr);
+    size_t n = 0;
+    bool far = false;
+    Planner(nloc, shard, bw, max_rb, split_lanes, wb, allow_relayout, keep_ghosts).skeleton(queue, &n, &far);
+    if (!have || (best_far && !far) || (best_far == far && n < best_n)) {
+      best_wb = wb;
+      best_n = n;
       best_far = far;
       have = true;
     }
-    if (best.sweeps.size() <= 1 && !best_far) break;
+    if (best_n <= 1 && !best_far) break;
   }
-  return best;
+  Planner chosen(nloc, shard, bw, max_rb, split_lanes, best_wb, allow_relayout, keep_ghosts);
+  // one sweep less?  Worth a search only where a sweep costs about what the search does: budget = the gate visits
+  // that fit into ~1.6 sweep times (2 x state bytes at 5.5 TB/s, ~2.5 ns per gate visit: 4 M visits = ~10 ms of host
+  // time for a 16-GiB state, hidden behind the GPU whenever circuits are submitted back to back, paid once per
+  // circuit with the plan cache on; eight supremacy-30 instances: 5 6 6 6 7 7 6 6 sweeps greedy, 4 6 5 5 6 6 5 5 with
+  // the search).  QH_PLAN_SEARCH=0 switches it off, QH_PLAN_SEARCH_STEPS pins the budget.
+  uint64_t dense_bits = 0;
+  for (const GateRec &q : queue) if (q.tgt >= 0 && q.tgt < nloc && !plan_diag(q.g, q.tgt)) dense_bits |= 1ull << q.tgt;
+  const int lane_low = bw == 128 ? 3 : 4;
+  const int cap = (kLaneBits - lane_low) + std::min({max_rb, max_reg_bits(bw), nloc - kLaneBits}) + best_wb;
+  const bool room = best_n >= 3 && popc(dense_bits >> lane_low) <= (int)(best_n - 1) * cap;   // every qubit visited at least once
+  if (room && env_flag("QH_PLAN_SEARCH", true)) {
+    const double sweep_us = 2.0 * (double)(bw == 128 ? 16 : 8) * (double)(1ull << nloc) / 5.5e6;
+    uint64_t budget = std::min<uint64_t>((uint64_t)(sweep_us * 650.0), 8000000);      // ~1.6 sweep times of host work, at most ~20 ms
+    if (const char *e = getenv("QH_PLAN_SEARCH_STEPS")) budget = strtoull(e, nullptr, 10);
+    if (budget >= 20000) {
+      std::vector<uint64_t> greedy;
+      size_t n = 0;
+      bool far = false;
+      Planner(nloc, shard, bw, max_rb, split_lanes, best_wb, allow_relayout, keep_ghosts).skeleton(queue, &n, &far, &greedy);
+      std::vector<std::vector<int>> tiles;
+      if (Planner(nloc, shard, bw, max_rb, split_lanes, best_wb, allow_relayout, keep_ghosts).search_tiles(queue, greedy, budget, &tiles)) {
+        Planner forced(nloc, shard, bw, max_rb, split_lanes, best_wb, allow_relayout, keep_ghosts);
+        forced.set_tiles(tiles);
+        PlanResult pr = forced.plan(queue);
+        if (pr.sweeps.size() < best_n && !plan_has_far_tile(pr)) return pr;     // (the model ignores relabelling: check)
+      }
+    }
+  }
+  return chosen.plan(queue);
 }
 
 inline std::string plan_to_json(const std::vector<GateRec> &queue, int nloc, uint64_t shard, int bw = 128,

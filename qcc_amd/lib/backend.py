@@ -166,6 +166,29 @@ def make_device_state(nbits, bit_width):
         return _default_device_factory(nbits, bit_width)
 
 
+def acquire_device_state(nbits, bit_width):
+    """A device state for a State's mirror (qcc_amd.lib.state): from the pool if one of that shape is parked."""
+    return make_device_state(nbits, bit_width)
+
+
+_state_mirror_forced = None
+
+
+def set_state_mirror(on):
+    """Test seam: True / False forces the State mirror on / off whatever executor is installed; None = the rule below."""
+    global _state_mirror_forced
+    _state_mirror_forced = on
+
+
+def state_mirror_allowed():
+    """State.apply1 / applyc may keep a device mirror only while the default host executor is in place (a test that
+    installed its own executor wants to see every call) and the process is not one rank of a sharded job."""
+    if _state_mirror_forced is not None:
+        return bool(_state_mirror_forced)
+    return ((_host_executor is None or type(_host_executor) is HipHostExecutor)  # pylint: disable=unidiomatic-typecheck
+            and int(os.environ.get('WORLD_SIZE', '1')) == 1)
+
+
 def set_device_factory(factory):
     global _device_factory
     _device_factory = factory

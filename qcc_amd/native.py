@@ -92,7 +92,8 @@ SIGNATURES = {
 
 class QhXStats(ctypes.Structure):
   _fields_ = [('exchanges', _u64), ('rounds', _u64), ('bytes_sent', _u64), ('slabs', _u64),
-              ('sweeps_overlapped', _u64), ('span_ms', ctypes.c_double), ('rounds_packed', _u64)]
+              ('sweeps_overlapped', _u64), ('span_ms', ctypes.c_double), ('rounds_packed', _u64),
+              ('geometry_checks', _u64), ('comm_ranks', ctypes.c_uint32), ('comm_rank', ctypes.c_uint32)]
 
   def as_dict(self):
     return {k: getattr(self, k) for k, _ in self._fields_}

@@ -345,8 +345,17 @@ class ShardedState(ShardRouter):
         self.eng.comm_init_custom(self.world, self.rank, round_fn)
         self.exchange_path = 'host-staged'
       else:
-        box = [self.eng.comm_unique_id() if self.rank == 0 else None]
+        # every rank runs the SAME collective sequence whatever happens on rank 0: it always broadcasts -- the id, or None
+        # and why it has none (librccl missing is the likeliest setup failure) -- and everybody meets in the MIN below
+        box = [None, None]
+        if self.rank == 0:
+          try:
+            box[0] = self.eng.comm_unique_id()
+          except Exception as e0:  # pylint: disable=broad-except
+            box[1] = f'{type(e0).__name__}: {e0}'
         dist.broadcast_object_list(box, src=0)
+        if box[0] is None:
+          raise TransportError(f'rank 0 could not create the RCCL unique id: {box[1]}')
         self.eng.comm_init(self.world, self.rank, box[0])
         self.exchange_path = 'rccl'
     except Exception as e:  # pylint: disable=broad-except
@@ -479,6 +488,8 @@ class ShardedState(ShardRouter):
       s['exchange_rounds'] = x['rounds'] - self._x0.get('rounds', 0)
       s['exchange_slabs'] = x['slabs'] - self._x0.get('slabs', 0)
       s['sweeps_overlapped_with_exchange'] = x['sweeps_overlapped'] - self._x0.get('sweeps_overlapped', 0)
+      s['exchange_geometry_checks'] = x.get('geometry_checks', 0)      # since the communicator was made (each distinct geometry once)
+      s['comm_ranks_reported'] = x.get('comm_ranks', 0)                # ncclCommCount / the host-staged transport's size
       if hasattr(self.eng, 'exchange_geometry') and self.exchanges:
         s['exchange_geometry'] = self.eng.exchange_geometry()
     return s

@@ -48,6 +48,9 @@ class OracleDevice:
 
   def download(self, offset=0, count=None, out=None):
     count = self.psi.size - offset if count is None else count
+    if out is not None:
+      out[:count] = self.psi[offset:offset + count]
+      return out
     return self.psi[offset:offset + count].copy()
 
   def apply1(self, gate, index):

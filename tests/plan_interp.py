@@ -52,9 +52,11 @@ def export_plan(handle):
           'lane_low': int(hdr[26]), 'relayout': int(hdr[27]), 'final_pos': final_pos}
     sp['dest_pos'] = [int(x) for x in raw[pos:pos + 64]]
     pos += 64
-    st = raw[pos:pos + 40].view('<i8')
-    pos += 40
-    sp['lanehi_store'], sp['wavepos_store'] = [int(x) for x in st[:3]], [int(x) for x in st[3:5]]
+    st = raw[pos:pos + 160].view('<i8')
+    pos += 160
+    sp['seat'], sp['seat_store'], sp['seat_dest'] = ([int(x) for x in st[:6]], [int(x) for x in st[6:12]],
+                                                      [int(x) for x in st[12:18]])
+    sp['wavepos_store'] = [int(x) for x in st[18:20]]
     kd = raw[pos:pos + 200].view('<i8')
     pos += 200
     sp['reg_dest'], sp['wave_dest'] = [int(x) for x in kd[:6]], [int(x) for x in kd[6:8]]
@@ -95,7 +97,8 @@ def run_plan(psi, sweeps, nloc, shard=0):
     rb = sp['rb']
     regpos = list(sp['regpos'][:rb])
     low = sp['lane_low']
-    lanepos = list(range(low)) + list(sp['lanehi'][:6 - low])
+    lanepos = list(sp['seat'])          # index bit on lane bit i: the line bits and lanehi, seated by cost (planner.h choose_seats)
+    assert sorted(lanepos) == sorted(list(range(low)) + list(sp['lanehi'][:6 - low])), 'seats are not the lane-resident bits'
     wavepos = list(sp['wavepos'][:sp['nwave']])
     fixed = np.uint64(sp['fixed_ones'])
     in_sweep = (idx & fixed) == fixed
@@ -195,9 +198,10 @@ def run_plan(psi, sweeps, nloc, shard=0):
       # the tile goes to the second buffer contiguously: lane bits on 0..5, register bit k on 6+k,
       # wave bit j on 6+rb+j, everything else above in order -- whatever the bits are now
       assert fixed == 0
-      assert lanepos[low:] == list(sp['lanehi_store'][:6 - low]) and wavepos == list(sp['wavepos_store'][:sp['nwave']])
+      assert lanepos == list(sp['seat_store']) and wavepos == list(sp['wavepos_store'][:sp['nwave']])
+      assert sorted(sp['seat_dest']) == list(range(6)), 'the lanes of the tile are not stored on positions 0..5'
       for k, b in enumerate(lanepos):
-        assert sp['dest_pos'][b] == k, 'the lanes of the tile are not stored on positions 0..5'
+        assert sp['dest_pos'][b] == sp['seat_dest'][k], 'store lane map disagrees with dest_pos'
       assert sorted(sp['dest_pos'][b] for b in regpos + wavepos) == list(range(6, 6 + len(regpos + wavepos))), \
           'the tile is not stored contiguously'
       assert sorted(sp['dest_pos'][:nloc]) == list(range(nloc)), 'dest_pos is not a permutation'
@@ -222,7 +226,7 @@ def run_plan(psi, sweeps, nloc, shard=0):
       psi[:] = permute_bits(psi, nloc, sp['dest_pos'])
       continue
     # in place: the tile is stored with `regpos_store`; lane exchanges must have been undone
-    assert lanepos == list(range(low)) + list(sp['lanehi'][:6 - low]), 'lane layout not restored before the store'
+    assert lanepos == list(sp['seat']) == list(sp['seat_store']), 'lane layout not restored before the store'
     assert sorted(regpos + wavepos) == sorted(list(sp['regpos'][:rb]) + list(sp['wavepos'][:sp['nwave']]))
   if sweeps and any(sp['relayout'] for sp in sweeps):
     fp = sweeps[0]['final_pos']

@@ -72,7 +72,7 @@ def test_ranks_with_other_planner_switches_are_told_apart(monkeypatch):
   b = _plan_ladder_point(34, 2, reps=1)[0]['geometries'][0]
   assert a['slabs'] == 8 and b['slabs'] == 4 and a['signature'] != b['signature']
   monkeypatch.delenv('QH_EXCHANGE_SLAB_BITS')
-  monkeypatch.setenv('QH_LSWAP_EARLY', '0')          # same slabs and rounds, another planner switch: still told apart
+  monkeypatch.setenv('QH_ROT_FUSE', '0')            # same slabs and rounds, another planner switch: still told apart
   c = _plan_ladder_point(34, 2, reps=1)[0]['geometries'][0]
   assert c['signature'] != a['signature']
 

@@ -67,3 +67,7 @@ def test_bench_multi_rank_launch_on_one_gpu(ranks):
   assert d['exchanges_per_step'] >= 1 and d['xgmi_bytes_per_rank_per_step'] > 0
   assert abs(d['norm2'] - 1) < 1e-10
   assert abs(d['value'] - 300 * 2 * 2 ** (24 - 30) / (d['ms_per_step'] * 2e-3)) / d['value'] < 1e-6
+  # correctness evidence inside the line: sampled amplitudes of one more QFT vs the closed form on every rank,
+  # what the communicator says about itself, and that the ranks compared their exchange geometry before data moved
+  assert d['parity_max_abs'] is not None and d['parity_max_abs'] < 1e-10 and d['parity_samples_per_rank'] == 64
+  assert d['rccl_ranks'] == ranks and d['exchange_verified'] is True and d['exchange_geometry_checks'] >= 1

@@ -11,8 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize('env', [{}, {'QH_WAVE_BITS': '2', 'QH_LANE_VALU': '2'}, {'QH_WAVE_BITS': '0', 'QH_SWEEP_RB': '4', 'QH_PROPAGATE_X': '0'},
-                                 {'QH_RELAYOUT': '0'}, {'QH_RELAYOUT_AHEAD': '0', 'QH_WAVE_BITS': '1'},
-                                 {'QH_ROT_FUSE': '0', 'QH_INLINE_GROUPS': '0'}])
+                                 {'QH_RELAYOUT': '0'}, {'QH_SEATS': '2', 'QH_WAVE_BITS': '1'},
+                                 {'QH_ROT_FUSE': '0', 'QH_SEATS': '0'}])
 def test_fuzz_fused_vs_oracle(env):
   e = dict(os.environ)
   e.update(env)

@@ -372,3 +372,94 @@ def test_device_pool_survives_the_cycle_collector(monkeypatch):
   assert len(backend._pool_order) == 1 and backend._pool_order[0].nbits == 9
   backend.drop_device_pool()
   assert not backend._pool_order and first.h is None
+
+
+def test_state_mirror_keeps_the_host_contract(monkeypatch):
+  """State.apply1 / applyc keep a device mirror (qcc_amd/lib/state.py): one upload, gates on the device, one download the
+  first time anything looks.  With the oracle stand-in as the device: whatever the caller does between the gates -- index,
+  slice, iterate, print, NumPy functions and operators, attributes that alias the buffer, copies, pickling, writes -- it
+  sees, and leaves, exactly what the literal per-call path (the reference's contract, state.py:80-125) would."""
+  import copy
+  import pickle
+  monkeypatch.setenv('QCC_STATE_MIRROR_MIN_QUBITS', '3')
+  rng = np.random.default_rng(5)
+  n = 7
+  looks = [
+      lambda p: p[3], lambda p: p[2:9].copy(), lambda p: list(p)[5], lambda p: repr(p), lambda p: str(p),
+      lambda p: np.abs(p).sum(), lambda p: np.vdot(p, p), lambda p: (p + 1)[0], lambda p: p @ p, lambda p: p.real[7],
+      lambda p: p.imag.sum(), lambda p: p.conj()[1], lambda p: p.sum(), lambda p: p.tolist()[3], lambda p: p.copy()[4],
+      lambda p: copy.deepcopy(p)[4], lambda p: pickle.loads(pickle.dumps(p))[6], lambda p: p.view(np.ndarray)[2],
+      lambda p: p.reshape(2, -1)[1, 3], lambda p: np.linalg.norm(p), lambda p: p.prob(0, 1, 0, 1, 0, 1, 1),
+      lambda p: p.maxprob(), lambda p: (p * state.ones(1))[9], lambda p: p.density()[2, 3], lambda p: p.tobytes()[:16],
+      lambda p: bytes(memoryview(p.data))[:16], lambda p: p.ctypes.data, lambda p: p.astype(np.complex64)[1],
+      lambda p: np.allclose(p, p), lambda p: p.normalize()[0], lambda p: float(np.real(p[1])), lambda p: 5 in p,
+      lambda p: np.concatenate([p, p])[130], lambda p: np.kron(p, [1, 0])[4], lambda p: p.ampl(1, 0, 1, 0, 1, 0, 1),
+  ]
+
+  def run(mirror):
+    backend.set_state_mirror(mirror)
+    state.mirror_stats(reset=True)
+    r = np.random.default_rng(77)
+    v = r.standard_normal(1 << n) + 1j * r.standard_normal(1 << n)
+    psi = state.State(v / np.linalg.norm(v))
+    seen = []
+    for step in range(3 * len(looks)):
+      for _ in range(int(r.integers(1, 6))):
+        g = ops.Operator((r.standard_normal((2, 2)) + 1j * r.standard_normal((2, 2))) / 1.6)
+        if r.random() < 0.5:
+          psi.apply1(g, int(r.integers(0, n)))
+        else:
+          c, t = (int(x) for x in r.choice(n, 2, replace=False))
+          psi.applyc(g, c, t)
+      out = looks[step % len(looks)](psi)
+      seen.append(np.asarray(out, dtype=object if isinstance(out, (str, bytes, tuple)) else None))
+      if step % 7 == 3:                     # the caller writes to the array between gates
+        psi[int(r.integers(0, 1 << n))] = 0.25
+      if step % 11 == 5:
+        psi *= 0.5
+    return np.array(psi), seen, state.mirror_stats()
+
+  try:
+    want, seen_w, st_w = run(False)
+    got, seen_g, st_g = run(True)
+  finally:
+    backend.set_state_mirror(None)
+  assert st_w['gates'] == 0 and st_g['gates'] > 250 and st_g['uploads'] == st_g['downloads'] == 3 * len(looks)
+  assert np.allclose(got, want, atol=1e-12)
+  for a, b in zip(seen_g, seen_w):
+    if a.dtype == object:
+      assert a.shape == b.shape and (a.tolist() == b.tolist() or isinstance(a.tolist(), int))   # (ctypes.data: an address)
+    else:
+      assert np.allclose(a.astype(np.complex128), b.astype(np.complex128), atol=1e-10)
+
+
+def test_state_mirror_moves_the_state_twice_for_a_run_of_gates(monkeypatch):
+  """40 direct apply calls = one upload + one download, views and copies never share a mirror, a State
+  that dies with gates pending downloads nothing."""
+  monkeypatch.setenv('QCC_STATE_MIRROR_MIN_QUBITS', '3')
+  backend.set_state_mirror(True)
+  try:
+    state.mirror_stats(reset=True)
+    psi = state.zeros(8)
+    ref = np.zeros(1 << 8, dtype=np.complex128)
+    ref[0] = 1
+    from tests import oracle_lib
+    o = oracle_lib.load()
+    for k in range(40):
+      psi.apply1(ops.Hadamard(), k % 8)
+      o.apply1(ref, np.asarray(ops.Hadamard()).reshape(4), 8, k % 8)
+      if k % 3 == 0:
+        psi.applyc(ops.PauliX(), k % 8, (k + 3) % 8)
+        o.applyc(ref, np.asarray(ops.PauliX()).reshape(4), 8, k % 8, (k + 3) % 8)
+    st = state.mirror_stats()
+    assert st['uploads'] == 1 and st['downloads'] == 0 and st['h2d_bytes'] == 16 << 8
+    assert np.allclose(np.asarray(psi[:]), ref, atol=1e-12)          # the first look: one download
+    st = state.mirror_stats()
+    assert st['downloads'] == 1 and st['d2h_bytes'] == 16 << 8 and st['gates'] == 54
+    v = psi[4:20]                                                    # a view has no mirror of its own
+    assert v._mirror is None
+    psi.apply1(ops.Hadamard(), 0)
+    del psi                                                          # dies with a gate pending: no download
+    assert state.mirror_stats()['downloads'] == 1 and state.mirror_stats()['uploads'] == 2
+  finally:
+    backend.set_state_mirror(None)

@@ -114,6 +114,22 @@ def price(sw, rb=5):
   return cost
 
 
+# Socket energy per wave-instruction by cost class, in nJ (profiles/r04/valu_power_per_instruction.txt: v_fma_f64 2.0, v_mul_f64 1.9,
+# v_add_f64 1.5, v_mov_b64 1.3, v_xor_b32 1.0, v_mov_b32_dpp 0.75, v_mov_b32 0.7, v_permlane*_swap 1.2): the op streams of an
+# op-heavy sweep run against the socket's power limit, so ENERGY, not the instruction count, is what a plan costs.
+ENERGY = {
+    'register butterflies': 1.5, 'register butterflies behind a pi/4 phase (fused)': 1.58, 'dense real (register)': 1.9,
+    'dense complex (register)': 1.95, 'lane butterflies by DPP': 1.0, 'lane real by DPP': 1.1, 'lane butterflies (LDS shuffles)': 1.5,
+    'lane dense (LDS shuffles)': 1.9, 'lane <-> register exchanges': 1.2, 'wave <-> register exchanges (LDS)': 1.0,
+    'factor trees': 1.95, 'sign on c': 1.0, 'sign groups': 1.0, 'factors joining c': 1.9, 'group prologues': 1.0,
+    'per-lane factor c on all slots': 1.95,
+}
+
+
+def energy(cost):
+  return sum(v * ENERGY.get(k, 1.95 if k.startswith('phase groups') else 1.5) for k, v in cost.items())
+
+
 def main():
   name = sys.argv[1] if len(sys.argv) > 1 else 'sup30'
   n, ops, g8 = workload(name)
@@ -127,7 +143,8 @@ def main():
       for k, v in c.most_common():
         print(f'    {v:6d}  {k}')
   print(f'{name}: {len(p["sweeps"])} sweeps, {sum(total.values())} VALU instructions per tile-circuit'
-        f' = {sum(total.values()) * (1 << (n - 11)) / 1e9:.2f} G wave-instructions')
+        f' = {sum(total.values()) * (1 << (n - 11)) / 1e9:.2f} G wave-instructions;'
+        f' {energy(total) / 1e3:.1f} uJ per tile-circuit = {energy(total) * (1 << (n - 11)) / 1e9:.1f} J per circuit (price list)')
   for k, v in total.most_common():
     print(f'  {v:6d}  {k}')
 
