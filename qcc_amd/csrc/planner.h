@@ -541,7 +541,7 @@ class Planner {
       }
       if (out.sweeps.back().relayout) {
         std::vector<int> ahead;
-        if (!rest.empty() && out.sweeps.size() < tiles_.size() && env_int("QH_AHEAD_FORCED", 1)) {
+        if (!rest.empty() && out.sweeps.size() < tiles_.size()) {
           // the next sweep's tile is already chosen (the tile search): those are the bits it will gather
           for (int b : tiles_[out.sweeps.size()])
             if (b >= lane_low_ && b < nloc_) ahead.push_back(out.final_pos[b]);
@@ -1657,11 +1657,8 @@ class Planner {
     int order[kLaneBits];
     for (int i = 0; i < kLaneBits; ++i) order[i] = sp->seat_store[i];
     std::sort(order, order + kLaneBits);
-    if (env_int("QH_STORE_ORDER", 1)) {     // (A/B) the bits the NEXT sweep's tile wants come first: its lane bits then sit lowest
-      uint64_t am = 0;
-      for (int p : ahead) if (p >= 0 && p < 64) am |= 1ull << p;
-      std::stable_sort(order, order + kLaneBits, [&](int a, int b) { return ((am >> a) & 1ull) > ((am >> b) & 1ull); });
-    }
+    // (tried: the bits the NEXT sweep's tile wants first among them, so that its lane bits sit lowest -- five supremacy-30
+    //  instances +0.7 / -0.6 / +1.0 / -2.2 / +0.6 %: nothing, profiles/r05/seats_ab3_summary.txt)
     for (int i = 0; i < kLaneBits; ++i) {
       const int b = order[i];
       if (b < sp->lane_low) { sp->dest_pos[b] = (uint8_t)b; placed |= 1ull << b; used |= 1ull << b; }
