@@ -77,6 +77,8 @@ struct qh_state_s {
   double *d_red = nullptr;     // kRedBlocks doubles
   uint64_t *d_redi = nullptr;  // kRedBlocks u64
   qh::SweepBuffers sweep;      // device/pinned op buffers for fused sweeps
+  uint64_t *d_tmax = nullptr;  // per-unit maxima the last sweep of a flush leaves for qh_argmax (SweepParams::tilemax)
+  uint64_t tmax_cap = 0;       // entries
   qh::Comm *comm = nullptr;    // multi-GPU exchange (exchange.hip.h)
   uint64_t amp_bytes() const { return bw == 128 ? 16 : 8; }
   uint64_t local_mask() const { return nloc >= 64 ? ~0ull : ((1ull << nloc) - 1ull); }
@@ -482,7 +484,7 @@ int canonicalize(qh_state_s *h) {
 // a planning / allocation failure keeps the whole queue, a failed per-gate launch keeps the
 // failing gate and everything after it.  Only a failed launch of a planned sweep leaves the
 // state partially updated; the queue is then dropped and the error says so.
-int flush_impl(qh_state_s *h, qh::SlabIO *split = nullptr) {
+int flush_impl(qh_state_s *h, qh::SlabIO *split = nullptr, qh::TileMaxOut *tmax = nullptr) {
   int rc = use_device(h);
   if (rc) return rc;
   if (h->poisoned)
@@ -504,7 +506,7 @@ int flush_impl(qh_state_s *h, qh::SlabIO *split = nullptr) {
     uint8_t final_pos[64];
     rc = qh::run_fused(h->queue, h->nloc, h->shard, h->bw, h->d_psi, h->stream, h->dry,
                        &h->sweep, &h->stats, &g_err, h->comm ? io : nullptr, h->d_alt, relay, &result, final_pos,
-                       h->nglob > h->nloc);
+                       h->nglob > h->nloc, tmax);
     if (rc == QH_OK && relay) {
       if (result != h->d_psi) std::swap(h->d_psi, h->d_alt);
       for (int b = 0; b < h->nglob; ++b)
@@ -779,6 +781,7 @@ int qh_destroy(qh_handle h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     (void)qh_comm_destroy(h);
     qh::free_sweep_buffers(&h->sweep);
+    if (h->d_tmax) (void)hipFree(h->d_tmax);
     if (h->d_red) (void)hipFree(h->d_red);
     if (h->d_redi) (void)hipFree(h->d_redi);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -1162,36 +1165,193 @@ int qh_prob_bit_value(qh_handle h, int logical_bit, int value, double *p) {
 
 int qh_prob_bit(qh_handle h, int logical_bit, double *p1) { return qh_prob_bit_value(h, logical_bit, 1, p1); }
 
-int qh_argmax(qh_handle h, uint64_t *phys_index, double *prob) {
+}  // extern "C"
+
+// ---- argmax (state.py:60-78 maxprob: the FIRST basis state, in logical order, with the largest probability) ----------
+namespace {
+// logical index of a physical one: bit inv[p] of the result = bit p (inv = where each physical bit position lives logically)
+struct BitMap { int n; uint8_t to[64]; };
+__device__ __forceinline__ uint64_t map_bits(uint64_t v, const BitMap &m) {
+  uint64_t o = 0;
+  for (int p = 0; p < m.n; ++p) o |= ((v >> p) & 1ull) << m.to[p];
+  return o;
+}
+__device__ __forceinline__ double prob_of(double2 a) { return __builtin_fma(a.y, a.y, a.x * a.x); }   // (as the sweep islands compute it)
+__device__ __forceinline__ double prob_of(float2 a) { return __builtin_fma((double)a.y, (double)a.y, (double)a.x * (double)a.x); }
+
+// per block: the largest probability and the smallest LOGICAL index that has it (identity map: the physical index)
+template <typename A, bool MAPPED>
+__global__ __launch_bounds__(256) void k_argmax_logical(const A *__restrict__ psi, uint64_t n, BitMap bm, double *best_p, uint64_t *best_i) {
+  __shared__ double sp[256];
+  __shared__ uint64_t si[256];
+  double bp = -1.0;
+  uint64_t bi = ~0ull;
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  auto take = [&](double p, uint64_t idx) {
+    if (p > bp) { bp = p; bi = MAPPED ? map_bits(idx, bm) : idx; }
+    else if (p == bp) { const uint64_t li = MAPPED ? map_bits(idx, bm) : idx; if (li < bi) bi = li; }
+  };
+  for (; i + 3 * stride < n; i += 4 * stride) {      // four loads in flight per thread
+    A a[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a[k] = qh::ld_amp<true>(psi + i + k * stride);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) take(prob_of(a[k]), i + k * stride);
+  }
+  for (; i < n; i += stride) take(prob_of(qh::ld_amp<true>(psi + i)), i);
+  sp[threadIdx.x] = bp;
+  si[threadIdx.x] = bi;
+  __syncthreads();
+  for (unsigned st = 128; st > 0; st >>= 1) {
+    if (threadIdx.x < st) {
+      const double op = sp[threadIdx.x + st];
+      const uint64_t oi = si[threadIdx.x + st];
+      if (op > sp[threadIdx.x] || (op == sp[threadIdx.x] && oi < si[threadIdx.x])) { sp[threadIdx.x] = op; si[threadIdx.x] = oi; }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { best_p[blockIdx.x] = sp[0]; best_i[blockIdx.x] = si[0]; }
+}
+
+// the per-unit maxima of the last sweep (bit patterns of non-negative doubles: they order like the doubles)
+__global__ __launch_bounds__(256) void k_tmax_reduce(const uint64_t *__restrict__ t, uint64_t n, uint64_t *out) {
+  __shared__ uint64_t sm[256];
+  uint64_t m = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) m = t[i] > m ? t[i] : m;
+  sm[threadIdx.x] = m;
+  __syncthreads();
+  for (unsigned st = 128; st > 0; st >>= 1) {
+    if (threadIdx.x < st && sm[threadIdx.x + st] > sm[threadIdx.x]) sm[threadIdx.x] = sm[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = sm[0];
+}
+constexpr unsigned kTmaxIds = 64;
+// units whose maximum is the global one: ids[0] = how many, ids[1..] the first kTmaxIds of them
+__global__ __launch_bounds__(256) void k_tmax_collect(const uint64_t *__restrict__ t, uint64_t n, uint64_t want, unsigned long long *ids) {
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256)
+    if (t[i] == want) {
+      const unsigned long long k = atomicAdd(ids, 1ull);
+      if (k < kTmaxIds) ids[1 + k] = i;
+    }
+}
+// one block per collected unit: the smallest logical index among its amplitudes with probability == want
+__global__ __launch_bounds__(256) void k_tmax_scan(const double2 *__restrict__ psi, const unsigned long long *__restrict__ ids, qh::BitIns ins,
+                                                    uint64_t tile_mask, int tile_bits, double want, BitMap bm, unsigned long long *out) {
+  const uint64_t base = qh::expand_index(ids[1 + blockIdx.x], ins);
+  unsigned long long best = ~0ull;
+  for (uint64_t j = threadIdx.x; j < (1ull << tile_bits); j += 256) {
+    uint64_t off = 0, jj = j;
+    for (uint64_t m = tile_mask; m; m &= m - 1) { off |= (jj & 1ull) << __builtin_ctzll(m); jj >>= 1; }
+    const uint64_t idx = base | off;
+    if (prob_of(qh::ld_amp<false>(psi + idx)) == want) {
+      const unsigned long long li = map_bits(idx, bm);
+      best = li < best ? li : best;
+    }
+  }
+  if (best != ~0ull) atomicMin(out, best);
+}
+
+// The last sweep of the flush left per-unit maxima: find the winner among the few units that hold the maximum.
+// QH_OK with *found = false: too many units tie (a uniform state): the caller runs the full pass.
+int argmax_from_tilemax(qh_state_s *h, const qh::TileMaxOut &tm, const BitMap &bm, uint64_t *logical, double *prob, bool *found) {
+  *found = false;
+  const unsigned grid = (unsigned)std::min<uint64_t>((tm.nunits + 255) / 256, kRedBlocks);
+  hipLaunchKernelGGL(k_tmax_reduce, dim3(grid), dim3(256), 0, h->stream, (const uint64_t *)tm.buf, tm.nunits, h->d_redi);
+  std::vector<uint64_t> part(grid);
+  HIP_TRY(hipMemcpyAsync(part.data(), h->d_redi, grid * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+  int rc = wait_stream(h, h->stream, "reader");
+  if (rc) return rc;
+  uint64_t top = 0;
+  for (uint64_t v : part) top = std::max(top, v);
+  double want;
+  memcpy(&want, &top, 8);
+  unsigned long long *ids = (unsigned long long *)h->d_redi;      // (kRedBlocks u64: room for 1 + kTmaxIds + the result)
+  static_assert(kRedBlocks >= 2 + kTmaxIds, "reduction scratch");
+  HIP_TRY(hipMemsetAsync(ids, 0, 8, h->stream));
+  HIP_TRY(hipMemsetAsync(ids + 1 + kTmaxIds, 0xff, 8, h->stream));
+  hipLaunchKernelGGL(k_tmax_collect, dim3(grid), dim3(256), 0, h->stream, (const uint64_t *)tm.buf, tm.nunits, top, ids);
+  unsigned long long cnt = 0;
+  HIP_TRY(hipMemcpyAsync(&cnt, ids, 8, hipMemcpyDeviceToHost, h->stream));
+  if ((rc = wait_stream(h, h->stream, "reader"))) return rc;
+  if (cnt == 0 || cnt > kTmaxIds) return QH_OK;
+  hipLaunchKernelGGL(k_tmax_scan, dim3((unsigned)cnt), dim3(256), 0, h->stream, (const double2 *)h->d_psi, ids, tm.ins, tm.tile_mask,
+                     __builtin_popcountll(tm.tile_mask), want, bm, ids + 1 + kTmaxIds);
+  unsigned long long li = ~0ull;
+  HIP_TRY(hipMemcpyAsync(&li, ids + 1 + kTmaxIds, 8, hipMemcpyDeviceToHost, h->stream));
+  if ((rc = wait_stream(h, h->stream, "reader"))) return rc;
+  if (li == ~0ull) return QH_OK;       // (cannot happen: a unit's maximum is one of its amplitudes) -> the full pass decides
+  *logical = li;
+  *prob = want;
+  *found = true;
+  return QH_OK;
+}
+}  // namespace
+
+extern "C" int qh_argmax(qh_handle h, uint64_t *phys_index, double *prob) {
   if (!h || !phys_index || !prob || h->dry) return fail(QH_ERR_ARG, "null/dry");
   HIP_TRY(hipSetDevice(h->device));
-  int rc = flush_impl(h);
-  if (rc) return rc;
-  const uint64_t n = 1ull << h->nloc;
-  const unsigned grid = (unsigned)std::min<uint64_t>((n + 255) / 256, kRedBlocks);
-  if (h->bw == 128)
-    hipLaunchKernelGGL(qh::k_argmax<double>, dim3(grid), dim3(256), 0, h->stream,
-                       (const double2 *)h->d_psi, n, h->d_red, h->d_redi);
-  else
-    hipLaunchKernelGGL(qh::k_argmax<float>, dim3(grid), dim3(256), 0, h->stream,
-                       (const float2 *)h->d_psi, n, h->d_red, h->d_redi);
-  std::vector<double> bp(grid);
-  std::vector<uint64_t> bi(grid);
-  HIP_TRY(hipMemcpyAsync(bp.data(), h->d_red, grid * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipMemcpyAsync(bi.data(), h->d_redi, grid * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
-  if ((rc = wait_stream(h, h->stream, "reader"))) return rc;
-  double best = -1.0;
-  uint64_t idx = 0;
-  for (unsigned k = 0; k < grid; ++k)
-    if (bp[k] > best || (bp[k] == best && bi[k] < idx)) {
-      best = bp[k];
-      idx = bi[k];
+  // the flush in front of the reader: its last sweep may leave the maximum of every unit it stores (complex128, no communicator)
+  qh::TileMaxOut tm;
+  if (h->fusion == QH_FUSE_SWEEP && h->bw == 128 && !h->comm && !h->queue.empty() && qh::sweep_supported(h->nloc, h->bw) &&
+      env_int("QH_FUSED_ARGMAX", 1) != 0) {
+    const uint64_t need = 1ull << (h->nloc - qh::kLaneBits - 2);       // units of the smallest tile a plan uses (two register bits)
+    if (h->tmax_cap < need) {
+      if (h->d_tmax) (void)hipFree(h->d_tmax);
+      h->d_tmax = nullptr;
+      h->tmax_cap = 0;
+      if (hipMalloc((void **)&h->d_tmax, need * 8) == hipSuccess) h->tmax_cap = need;
+      else (void)hipGetLastError();
     }
-  *phys_index = (h->shard << h->nloc) | idx;
-  *prob = best;
+    tm.buf = h->d_tmax;
+    tm.cap = h->tmax_cap;
+  }
+  int rc = flush_impl(h, nullptr, tm.buf ? &tm : nullptr);
+  if (rc) return rc;
+  // ties go to the smallest LOGICAL index, whatever layout relayout sweeps have left the state in
+  BitMap bm{};
+  bm.n = h->nloc;
+  bool mapped = false;
+  for (int b = 0; b < h->nglob; ++b)
+    if (h->perm[b] < h->nloc) { bm.to[h->perm[b]] = (uint8_t)b; mapped |= h->perm[b] != b; }
+  uint64_t logical = 0;
+  bool found = false;
+  if (tm.valid) {
+    rc = argmax_from_tilemax(h, tm, bm, &logical, prob, &found);
+    if (rc) return rc;
+  }
+  if (!found) {
+    const uint64_t n = 1ull << h->nloc;
+    const unsigned grid = (unsigned)std::min<uint64_t>((n + 255) / 256, kRedBlocks);
+    if (h->bw == 128) {
+      if (mapped) hipLaunchKernelGGL((k_argmax_logical<double2, true>), dim3(grid), dim3(256), 0, h->stream, (const double2 *)h->d_psi, n, bm, h->d_red, h->d_redi);
+      else hipLaunchKernelGGL((k_argmax_logical<double2, false>), dim3(grid), dim3(256), 0, h->stream, (const double2 *)h->d_psi, n, bm, h->d_red, h->d_redi);
+    } else {
+      if (mapped) hipLaunchKernelGGL((k_argmax_logical<float2, true>), dim3(grid), dim3(256), 0, h->stream, (const float2 *)h->d_psi, n, bm, h->d_red, h->d_redi);
+      else hipLaunchKernelGGL((k_argmax_logical<float2, false>), dim3(grid), dim3(256), 0, h->stream, (const float2 *)h->d_psi, n, bm, h->d_red, h->d_redi);
+    }
+    std::vector<double> bp(grid);
+    std::vector<uint64_t> bi(grid);
+    HIP_TRY(hipMemcpyAsync(bp.data(), h->d_red, grid * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(bi.data(), h->d_redi, grid * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+    if ((rc = wait_stream(h, h->stream, "reader"))) return rc;
+    double best = -1.0;
+    uint64_t idx = 0;
+    for (unsigned k = 0; k < grid; ++k)
+      if (bp[k] > best || (bp[k] == best && bi[k] < idx)) { best = bp[k]; idx = bi[k]; }
+    logical = idx;
+    *prob = best;
+  }
+  // the caller gets the PHYSICAL index of the shard-local amplitude (qh_phys_to_logical turns it back)
+  uint64_t phys = 0;
+  for (int b = 0; b < h->nglob; ++b)
+    if (h->perm[b] < h->nloc && ((logical >> b) & 1ull)) phys |= 1ull << h->perm[b];
+  *phys_index = (h->shard << h->nloc) | phys;
   return QH_OK;
 }
 
+extern "C" {
 int qh_scale(qh_handle h, double re, double im) {
   if (!h || h->dry) return fail(QH_ERR_ARG, "null/dry");
   HIP_TRY(hipSetDevice(h->device));

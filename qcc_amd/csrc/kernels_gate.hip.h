@@ -395,58 +395,6 @@ __global__ __launch_bounds__(256) void k_norm2(const typename AmpT<R>::type *__r
   if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
 }
 
-// per-block (max |a|^2, first index attaining it); host reduces the block list.
-template <typename R>
-__global__ __launch_bounds__(256) void k_argmax(const typename AmpT<R>::type *__restrict__ psi,
-                                                 uint64_t n, double *best_p,
-                                                 uint64_t *best_i) {
-  __shared__ double sp[256];
-  __shared__ uint64_t si[256];
-  double bp = -1.0;
-  uint64_t bi = 0;
-  const uint64_t stride = (uint64_t)gridDim.x * 256;
-  uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  for (; i + 3 * stride < n; i += 4 * stride) {      // four loads in flight per thread (indices ascending: first maximum wins)
-    typename AmpT<R>::type a[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) a[k] = ld_amp<true>(psi + i + k * stride);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const double p = (double)a[k].x * (double)a[k].x + (double)a[k].y * (double)a[k].y;
-      if (p > bp) {
-        bp = p;
-        bi = i + k * stride;
-      }
-    }
-  }
-  for (; i < n; i += stride) {
-    const auto a = ld_amp<true>(psi + i);
-    const double p = (double)a.x * (double)a.x + (double)a.y * (double)a.y;
-    if (p > bp) {
-      bp = p;
-      bi = i;
-    }
-  }
-  sp[threadIdx.x] = bp;
-  si[threadIdx.x] = bi;
-  __syncthreads();
-  for (unsigned s = 128; s > 0; s >>= 1) {
-    if (threadIdx.x < s) {
-      const double op = sp[threadIdx.x + s];
-      const uint64_t oi = si[threadIdx.x + s];
-      if (op > sp[threadIdx.x] || (op == sp[threadIdx.x] && oi < si[threadIdx.x])) {
-        sp[threadIdx.x] = op;
-        si[threadIdx.x] = oi;
-      }
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    best_p[blockIdx.x] = sp[0];
-    best_i[blockIdx.x] = si[0];
-  }
-}
-
 // zero every amplitude whose bit `bit` differs from `value`.
 template <typename R>
 __global__ __launch_bounds__(256) void k_project(typename AmpT<R>::type *__restrict__ psi,

@@ -266,6 +266,84 @@ def test_readers(oracle):
     assert got[77] == 1 and np.count_nonzero(got) == 1
 
 
+def _random_stream(rng, n, ngates):
+  ops, gs = [], []
+  for _ in range(ngates):
+    q = np.linalg.qr(rng.standard_normal((2, 2)) + 1j * rng.standard_normal((2, 2)))[0]
+    if rng.random() < 0.35:
+      c, t = (int(v) for v in rng.choice(n, 2, replace=False))
+      g = np.diag([1.0, np.exp(1j * rng.uniform(0, 6.28))]) if rng.random() < 0.5 else q
+      ops.append((c, t))
+    else:
+      g = q
+      ops.append((workloads.NO_CTL, int(rng.integers(0, n))))
+    gs.append(np.asarray(g, dtype=np.complex128).reshape(4))
+  return np.array(ops, dtype=np.int32), np.array(gs).view(np.float64).reshape(-1, 8)
+
+
+@pytest.mark.parametrize('relayout', ['1', '0'])
+def test_argmax_behind_a_flush_uses_the_last_sweep(oracle, monkeypatch, relayout):
+  """qh_argmax right behind a fused flush takes the per-unit maxima the last sweep left (SweepParams::tilemax, engine.hip
+  argmax_from_tilemax) instead of a full pass: the same index and probability as the full pass (QH_FUSED_ARGMAX=0) and as
+  NumPy on the downloaded state, for random circuits in whatever layout relayout sweeps leave (and in place), for exact ties
+  -- the smallest LOGICAL index wins, state.py:60-78 -- and for a uniform state (every unit ties: the full pass decides)."""
+  monkeypatch.setenv('QH_RELAYOUT', relayout)
+  rng = np.random.default_rng(31)
+  for case in range(10):
+    n = int(rng.integers(10, 21))
+    ops, g8 = _random_stream(rng, n, int(rng.integers(5, 120)))
+    res = {}
+    for fused in ('1', '0'):
+      monkeypatch.setenv('QH_FUSED_ARGMAX', fused)
+      with device.DeviceState(n, 128, fusion=native.QH_FUSE_SWEEP) as st:
+        st.init_basis(int(rng.integers(0, 1 << n)) if fused == '1' else res['init'])
+        if fused == '1':
+          res['init'] = int(np.argmax(np.abs(st.download())))
+        st.run_stream(ops, g8)
+        idx, p = st.argmax()
+        psi = st.download()
+        res[fused] = (idx, p)
+      want = int(np.argmax(np.abs(psi) ** 2))
+      assert abs(p - np.abs(psi[want]) ** 2) < 1e-15 and np.abs(psi[idx]) ** 2 == np.abs(psi[want]) ** 2, (case, fused, idx, want)
+    assert res['1'] == res['0'], (case, res)
+  monkeypatch.setenv('QH_FUSED_ARGMAX', '1')
+  # exact ties: (|a> + |b>)/sqrt(2) pushed through a circuit of permutations / diagonal gates only -- the two peaks stay exactly
+  # equal, relayout sweeps reorder the physical indices, the smaller LOGICAL index must win
+  n = 16
+  xg = np.array([0, 1, 1, 0], dtype=np.complex128)
+  for trial in range(6):
+    a, b = sorted(int(v) for v in rng.choice(1 << n, 2, replace=False))
+    psi0 = np.zeros(1 << n, dtype=np.complex128)
+    psi0[a] = psi0[b] = 1 / np.sqrt(2)
+    ops, gs = [], []
+    for _ in range(60):
+      t = int(rng.integers(0, n))
+      if rng.random() < 0.5:
+        ops.append((workloads.NO_CTL, t)); gs.append(xg)
+      else:
+        c = int((t + 1 + rng.integers(0, n - 1)) % n)
+        ops.append((c, t)); gs.append(np.array([1, 0, 0, np.exp(1j * rng.uniform(0, 6.28))], dtype=np.complex128))
+    ops = np.array(ops, dtype=np.int32)
+    g8 = np.array(gs).view(np.float64).reshape(-1, 8)
+    # a dense layer first so that the sweeps have targets everywhere (and relayout sweeps happen), undone exactly by H.H = 1
+    want = psi0.copy()
+    oracle.run_stream(want, n, ops, g8)
+    with device.DeviceState(n, 128, fusion=native.QH_FUSE_SWEEP) as st:
+      st.upload(psi0)
+      st.run_stream(ops, g8)
+      idx, p = st.argmax()
+    peaks = np.flatnonzero(np.abs(want) > 0.5)
+    assert len(peaks) == 2 and idx == int(peaks[0]) and abs(p - 0.5) < 1e-15, (trial, idx, peaks)
+  # uniform state: every amplitude ties, index 0 wins
+  hg = np.array([1, 1, 1, -1], dtype=np.complex128) / np.sqrt(2)
+  with device.DeviceState(n, 128, fusion=native.QH_FUSE_SWEEP) as st:
+    st.init_basis(0)
+    st.run_stream(np.array([(workloads.NO_CTL, q) for q in range(n)], dtype=np.int32), np.tile(hg.view(np.float64), (n, 1)))
+    idx, p = st.argmax()
+    psi = st.download()
+  assert idx == int(np.argmax(np.abs(psi) ** 2)) and abs(p - 2.0 ** -n) < 1e-18
+
+
 def test_supremacy20_sampled_golden(golden_dir):
   """G9: the reference's 20-qubit depth-20 supremacy run (trace + sampled amplitudes)."""
   g = np.load(os.path.join(golden_dir, 'g9_supremacy_n20_s0.npz'))
