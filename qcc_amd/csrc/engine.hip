@@ -18,7 +18,6 @@
 #include <cstring>
 #include <ctime>
 #include <string>
-#include <thread>
 #include <vector>
 
 #include "../../include/qcc_hip.h"
@@ -59,11 +58,6 @@ struct qh_state_s {
   void *host_psi = nullptr;    // qh_create_host_mapped: the pinned, GPU-visible host allocation d_psi points into
   void *d_alt = nullptr;       // second buffer of the same size: target of relayout sweeps (lazily allocated)
   int relayout = -1;           // -1 undecided, 0 off (attached memory, no room, QH_RELAYOUT=0), 1 on
-  // The second buffer of a large owning handle is requested by a helper thread the moment the handle is created (a 16-GiB
-  // allocation takes 0.2 ms - 3 s, contiguous ones longer): register construction, gate submission and planning overlap it,
-  // and the first flush that wants the buffer only waits for what is left (alloc_second_buffer joins).
-  std::thread alt_thread;
-  void *alt_early = nullptr;   // what the helper got (nullptr: refused)
   bool owns_mem = false, owns_stream = false, dry = false;
   bool poisoned = false;       // a sweep of a flush failed after others had run: the amplitudes are undefined until re-initialised
   hipStream_t stream = nullptr;
@@ -405,29 +399,8 @@ bool second_buffer_fits(const qh_state_s *h, size_t bytes) {
   const size_t reserve = (bytes >> 5) + (3ull << 29) + ((h->comm && h->comm->nranks > 1) ? (4ull << 30) : 0);
   return hipMemGetInfo(&fr, &total) == hipSuccess && fr > bytes + reserve;
 }
-void join_early_alloc(qh_state_s *h) {
-  if (h->alt_thread.joinable()) h->alt_thread.join();
-}
-// qh_create: large owning handles ask for their second buffer at once, on a helper thread (QH_PREALLOC=0: never)
-thread_local bool g_no_early_alloc = false;     // (the per-thread scratch handles of the literal drop-in never use a second buffer)
-void start_early_alloc(qh_state_s *h) {
-  const size_t bytes = (size_t)h->amp_bytes() << h->nloc;
-  if (g_no_early_alloc || bytes < (1ull << 30) || env_int("QH_PREALLOC", 1) == 0 || !relayout_eligible(h) || !second_buffer_fits(h, bytes)) return;
-  const int device = h->device;
-  h->alt_thread = std::thread([h, bytes, device] {
-    void *p = nullptr;
-    if (hipSetDevice(device) == hipSuccess && alloc_state_buffer(&p, bytes) == hipSuccess) h->alt_early = p;
-    else (void)hipGetLastError();
-  });
-}
 bool alloc_second_buffer(qh_state_s *h) {
   if (h->d_alt) return true;
-  join_early_alloc(h);
-  if (h->alt_early) {
-    h->d_alt = h->alt_early;
-    h->alt_early = nullptr;
-    return true;
-  }
   const size_t bytes = (size_t)h->amp_bytes() << h->nloc;
   if (second_buffer_fits(h, bytes) && alloc_state_buffer(&h->d_alt, bytes) == hipSuccess)
     return true;
@@ -550,8 +523,6 @@ int set_relayout(qh_state_s *h, bool on, int *actual = nullptr) {
     rc = flush_impl(h);
     if (rc == QH_OK) rc = canonicalize(h);
     if (rc) return rc;
-    join_early_alloc(h);
-    if (h->alt_early) { (void)hipFree(h->alt_early); h->alt_early = nullptr; }
     if (h->d_alt) {
       HIP_TRY(hipStreamSynchronize(h->stream));
       (void)hipFree(h->d_alt);
@@ -691,7 +662,6 @@ int qh_create(int nbits, int bit_width, int device, qh_handle *out) {
     qh_destroy(h);
     return rc;
   }
-  start_early_alloc(h);
   *out = h;
   return QH_OK;
 }
@@ -776,8 +746,6 @@ int qh_destroy(qh_handle h) {
   if (h->dry) (void)qh_comm_destroy(h);
   if (!h->dry) {
     (void)hipSetDevice(h->device);
-    join_early_alloc(h);
-    if (h->alt_early) (void)hipFree(h->alt_early);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     (void)qh_comm_destroy(h);
     qh::free_sweep_buffers(&h->sweep);
@@ -1184,13 +1152,25 @@ template <typename A, bool MAPPED>
 __global__ __launch_bounds__(256) void k_argmax_logical(const A *__restrict__ psi, uint64_t n, BitMap bm, double *best_p, uint64_t *best_i) {
   __shared__ double sp[256];
   __shared__ uint64_t si[256];
+  // physical -> logical through five byte tables (a near-uniform state -- a QFT's output -- ties at almost every amplitude:
+  // the bit-by-bit map there cost 10 ms of a 30-qubit pass)
+  __shared__ uint64_t lut[MAPPED ? 5 * 256 : 1];
+  if (MAPPED) {
+    for (int t = 0; t < 5; ++t) lut[t * 256 + threadIdx.x] = map_bits((uint64_t)threadIdx.x << (8 * t), bm);
+    __syncthreads();
+  }
+  auto logical = [&](uint64_t idx) -> uint64_t {
+    if (!MAPPED) return idx;
+    return lut[idx & 255] | lut[256 + ((idx >> 8) & 255)] | lut[512 + ((idx >> 16) & 255)] | lut[768 + ((idx >> 24) & 255)] |
+           lut[1024 + ((idx >> 32) & 255)];
+  };
   double bp = -1.0;
   uint64_t bi = ~0ull;
   const uint64_t stride = (uint64_t)gridDim.x * 256;
   uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   auto take = [&](double p, uint64_t idx) {
-    if (p > bp) { bp = p; bi = MAPPED ? map_bits(idx, bm) : idx; }
-    else if (p == bp) { const uint64_t li = MAPPED ? map_bits(idx, bm) : idx; if (li < bi) bi = li; }
+    if (p > bp) { bp = p; bi = logical(idx); }
+    else if (p == bp) { const uint64_t li = logical(idx); if (li < bi) bi = li; }
   };
   for (; i + 3 * stride < n; i += 4 * stride) {      // four loads in flight per thread
     A a[4];
@@ -1253,8 +1233,19 @@ __global__ __launch_bounds__(256) void k_tmax_scan(const double2 *__restrict__ p
   if (best != ~0ull) atomicMin(out, best);
 }
 
-// The last sweep of the flush left per-unit maxima: find the winner among the few units that hold the maximum.
-// QH_OK with *found = false: too many units tie (a uniform state): the caller runs the full pass.
+// the smallest logical index in [l0, l1) whose amplitude has probability == want (l2p: logical -> physical)
+__global__ __launch_bounds__(256) void k_prefix_scan(const double2 *__restrict__ psi, uint64_t l0, uint64_t l1, double want, BitMap l2p,
+                                                      unsigned long long *out) {
+  unsigned long long best = ~0ull;
+  for (uint64_t l = l0 + (uint64_t)blockIdx.x * 256 + threadIdx.x; l < l1; l += (uint64_t)gridDim.x * 256)
+    if (prob_of(qh::ld_amp<false>(psi + map_bits(l, l2p))) == want) { best = l; break; }     // (ascending per thread: the first hit is its smallest)
+  if (best != ~0ull) atomicMin(out, best);
+}
+
+// The last sweep of the flush left per-unit maxima: the largest of them is the answer's probability; the answer's index is the
+// smallest logical index that has it.  Few units hold it (a peaked state: Grover, most algorithms' outputs): those units are
+// scanned.  Many do (a flat state: a QFT's output ties at a tenth of its amplitudes): the first of them in LOGICAL order is
+// near the start -- growing prefixes of the logical index range are scanned until one has a hit.  Exact either way.
 int argmax_from_tilemax(qh_state_s *h, const qh::TileMaxOut &tm, const BitMap &bm, uint64_t *logical, double *prob, bool *found) {
   *found = false;
   const unsigned grid = (unsigned)std::min<uint64_t>((tm.nunits + 255) / 256, kRedBlocks);
@@ -1275,7 +1266,28 @@ int argmax_from_tilemax(qh_state_s *h, const qh::TileMaxOut &tm, const BitMap &b
   unsigned long long cnt = 0;
   HIP_TRY(hipMemcpyAsync(&cnt, ids, 8, hipMemcpyDeviceToHost, h->stream));
   if ((rc = wait_stream(h, h->stream, "reader"))) return rc;
-  if (cnt == 0 || cnt > kTmaxIds) return QH_OK;
+  if (cnt == 0) return QH_OK;
+  if (cnt > kTmaxIds) {
+    BitMap l2p{};
+    l2p.n = h->nloc;
+    for (int p = 0; p < h->nloc; ++p) l2p.to[bm.to[p]] = (uint8_t)p;       // (bm: physical -> logical, a permutation of the local bits)
+    const uint64_t n = 1ull << h->nloc;
+    uint64_t l0 = 0;
+    for (uint64_t l1 = std::min<uint64_t>(n, 1ull << 16); l0 < n; l0 = l1, l1 = std::min<uint64_t>(n, l1 << 6)) {
+      const unsigned g = (unsigned)std::min<uint64_t>((l1 - l0 + 255) / 256, 1u << 16);
+      hipLaunchKernelGGL(k_prefix_scan, dim3(g), dim3(256), 0, h->stream, (const double2 *)h->d_psi, l0, l1, want, l2p, ids + 1 + kTmaxIds);
+      unsigned long long hit = ~0ull;
+      HIP_TRY(hipMemcpyAsync(&hit, ids + 1 + kTmaxIds, 8, hipMemcpyDeviceToHost, h->stream));
+      if ((rc = wait_stream(h, h->stream, "reader"))) return rc;
+      if (hit != ~0ull) {
+        *logical = hit;
+        *prob = want;
+        *found = true;
+        return QH_OK;
+      }
+    }
+    return QH_OK;      // (cannot happen)
+  }
   hipLaunchKernelGGL(k_tmax_scan, dim3((unsigned)cnt), dim3(256), 0, h->stream, (const double2 *)h->d_psi, ids, tm.ins, tm.tile_mask,
                      __builtin_popcountll(tm.tile_mask), want, bm, ids + 1 + kTmaxIds);
   unsigned long long li = ~0ull;
@@ -2120,9 +2132,7 @@ static int host_handle(int nbits, int bw, qh_handle *out) {
   if (g_host.slot[1]) qh_destroy(g_host.slot[1]);
   g_host.slot[1] = g_host.slot[0];
   g_host.slot[0] = nullptr;
-  g_no_early_alloc = true;
   int rc = qh_create(nbits, bw, 0, &g_host.slot[0]);
-  g_no_early_alloc = false;
   if (rc) return rc;
   g_host.slot[0]->relayout = 0;   // one gate per call: nothing to gain from a second buffer
   *out = g_host.slot[0];

@@ -322,10 +322,9 @@ def test_argmax_behind_a_flush_uses_the_last_sweep(oracle, monkeypatch, relayout
         ops.append((workloads.NO_CTL, t)); gs.append(xg)
       else:
         c = int((t + 1 + rng.integers(0, n - 1)) % n)
-        ops.append((c, t)); gs.append(np.array([1, 0, 0, np.exp(1j * rng.uniform(0, 6.28))], dtype=np.complex128))
+        ops.append((c, t)); gs.append(np.array([1, 0, 0, (1, 1j, -1, -1j)[int(rng.integers(0, 4))]], dtype=np.complex128))   # (exact: the peaks stay equal)
     ops = np.array(ops, dtype=np.int32)
     g8 = np.array(gs).view(np.float64).reshape(-1, 8)
-    # a dense layer first so that the sweeps have targets everywhere (and relayout sweeps happen), undone exactly by H.H = 1
     want = psi0.copy()
     oracle.run_stream(want, n, ops, g8)
     with device.DeviceState(n, 128, fusion=native.QH_FUSE_SWEEP) as st:
