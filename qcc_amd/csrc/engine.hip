@@ -373,14 +373,15 @@ bool relayout_wanted(const qh_state_s *h) {
 // hipMalloc.  Measured, not derived (DESIGN 7 "placement", profiles/r03/alloc_contiguous_*): where the driver puts a
 // buffer decides +-2.5 % of a sweep's time; contiguous 8- and 16-GiB buffers land in the fast mode 11 times of 12
 // (30-qubit QFT 16.54 ms mean vs 16.92 over 12 interleaved fresh processes), a contiguous 256-GiB state is 6 % slower.
-hipError_t alloc_state_buffer(void **p, size_t bytes, bool second = false) {
+// (round 5, profiles/r05/alloc_second_buffer_ab.txt: on that box plain buffers cost 1.3-1.5 ms of a 17-ms QFT, a plain SECOND
+// buffer 0.5-1.2; and the seconds an allocation sometimes takes are not the contiguous search -- any allocation that follows the
+// release of a 128- or 256-GiB state pays ~6.2 s of driver work, plain ones too.)
+hipError_t alloc_state_buffer(void **p, size_t bytes) {
   static const int contig = env_int("QH_ALLOC_CONTIG", -1), debug = env_int("QH_ALLOC_DEBUG", 0);
   const auto t0 = std::chrono::steady_clock::now();
   hipError_t e = hipErrorOutOfMemory;
   bool got_contig = false;
-  // (QH_ALLOC_CONTIG=2, experiment: the first buffer of a handle contiguous by the auto rule, its second buffer plain)
-  const bool want_contig = (contig == 2 && second) ? false
-                           : (contig < 0 || contig == 2) ? (bytes >= (4ull << 30) && bytes <= (32ull << 30)) : (contig > 0 && bytes >= (64ull << 20));
+  const bool want_contig = contig < 0 ? (bytes >= (4ull << 30) && bytes <= (32ull << 30)) : (contig > 0 && bytes >= (64ull << 20));
   if (want_contig) {
     e = hipExtMallocWithFlags(p, bytes, hipDeviceMallocContiguous);
     got_contig = e == hipSuccess;
@@ -404,7 +405,7 @@ bool second_buffer_fits(const qh_state_s *h, size_t bytes) {
 bool alloc_second_buffer(qh_state_s *h) {
   if (h->d_alt) return true;
   const size_t bytes = (size_t)h->amp_bytes() << h->nloc;
-  if (second_buffer_fits(h, bytes) && alloc_state_buffer(&h->d_alt, bytes, true) == hipSuccess)
+  if (second_buffer_fits(h, bytes) && alloc_state_buffer(&h->d_alt, bytes) == hipSuccess)
     return true;
   (void)hipGetLastError();
   h->d_alt = nullptr;
