@@ -283,10 +283,13 @@ def config_line(name, n, bw, ops, g8, init, device_index, steps, warmup, note, t
     eng = device.DeviceState(n, bw, device=device_index, fusion=native.QH_FUSE_SWEEP)
   except native.QhError as e:
     return {'workload': name, 'qubits': n, 'skipped': str(e)}
-  with eng:
-    eng.init_basis(init)
-    wall, ev_ms, st = timed_steps(eng, ops, g8, steps, warmup, None)
-    norm2 = eng.norm2()
+  try:
+    with eng:
+      eng.init_basis(init)
+      wall, ev_ms, st = timed_steps(eng, ops, g8, steps, warmup, None)
+      norm2 = eng.norm2()
+  except native.QhError as e:         # (one entry's failure must not cost the line)
+    return {'workload': name, 'qubits': n, 'error': str(e)}
   launches = max(1, st['kernels_launched'])
   bytes_l = st['bytes_swept'] / launches
   ms_l = ev_ms / launches
@@ -391,6 +394,10 @@ def single_shot(device_index):
     out['error'] = repr(e)
   finally:
     tensor.set_tensor_width(None)
+    # the circuits above parked their device states (two 16-GiB buffers each) for the next circuit of that shape:
+    # the 128- and 256-GiB states that follow need the room
+    from qcc_amd.lib import backend
+    backend.drop_device_pool()
   return out
 
 
