@@ -1311,7 +1311,8 @@ extern "C" int qh_argmax(qh_handle h, uint64_t *phys_index, double *prob) {
   qh::TileMaxOut tm;
   if (h->fusion == QH_FUSE_SWEEP && h->bw == 128 && !h->comm && !h->queue.empty() && qh::sweep_supported(h->nloc, h->bw) &&
       env_int("QH_FUSED_ARGMAX", 1) != 0) {
-    const uint64_t need = 1ull << (h->nloc - qh::kLaneBits - 2);       // units of the smallest tile a plan uses (two register bits)
+    const uint64_t need = 1ull << (h->nloc - qh::kLaneBits - 3);       // units of a three-register-bit tile (a sweep without dense gates); plans
+                                                                       // with dense gates use five: a flush that wants more entries takes the full pass
     if (h->tmax_cap < need) {
       if (h->d_tmax) (void)hipFree(h->d_tmax);
       h->d_tmax = nullptr;

@@ -836,7 +836,9 @@ class Planner {
     if (need_move > 0 && other[0] >= 17 && lanes_high_) {
       // every candidate is above the 2-MiB page (each line of a load in another page anyway):
       // then the HIGHEST bits (up to kMaxLaneHiBit: lane offsets are 32-bit byte offsets) make
-      // the better lane bits (tools/geom_scan_wave1.py, targets 21..29: 6.9 ms vs 7.25 ms)
+      // the better lane bits (tools/geom_scan_wave1.py, targets 21..29: 6.9 ms vs 7.25 ms; tried again in round 5 on
+      // Grover-34's far tiles, targets 17..26: lowest bits as lanes 101 ms instead of 103 per sweep, highest bits as waves
+      // 103-105: within 2 %, rule kept -- profiles/r05/grover34_per_sweep.txt)
       std::vector<int> rest;
       int moved = 0;
       for (size_t k = other.size(); k-- > 0;) {
