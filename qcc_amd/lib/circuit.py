@@ -274,7 +274,7 @@ class qc:
                 self._dev.init_product(self._factors)
             else:
                 assert self._host_ok, 'no valid copy of the state'
-                self._dev.upload(np.asarray(self._host))
+                self._dev.upload(np.asarray(tensor.host_current(self._host)))
             self._dev_ok = True
             if self._aliased():
                 self._host, self._host_ok = None, False   # from now on THE state is the mapped buffer
@@ -321,7 +321,7 @@ class qc:
     def psi(self, value):
         if self._q_ops:
             self._drain()
-        host = value if isinstance(value, state.State) else state.State(value)
+        host = tensor.host_current(value) if isinstance(value, state.State) else state.State(value)
         if host.dtype != tensor.tensor_type():
             host = state.State(host)
         if (self._aliased() and self._dev is not None and self._dev_ok and host.ndim and host.nbits == self._nbits
@@ -340,7 +340,7 @@ class qc:
         """psi <- psi (x) new_state (circuit.py:121-123)."""
         if self._is_product:
             idx = getattr(new_state, 'basis_index', None)
-            self._append_factor(nqubits, idx if idx is not None else np.array(new_state, dtype=np.complex128))
+            self._append_factor(nqubits, idx if idx is not None else np.array(tensor.host_current(new_state), dtype=np.complex128))
             return
         cur = self.psi if self._nbits else state.State(1.0)
         self.psi = cur * new_state

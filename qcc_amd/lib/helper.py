@@ -80,6 +80,9 @@ def density_to_cartesian(rho):
 
 
 def qubit_to_bloch(psi):
+    sync = getattr(psi, '_sync_host', None)      # (a State with gates on its device mirror: qcc_amd/lib/state.py)
+    if sync is not None:
+        sync()
     psi = np.asarray(psi)
     return density_to_cartesian(np.outer(psi, psi.conj()))
 

@@ -186,7 +186,7 @@ def Measure(psi, idx, tostate=0, collapse=True):
     (ops.py:426-460) but O(2^n): a masked norm instead of a 4^n density matrix."""
     n = psi.nbits
     bit = n - 1 - idx
-    amp = np.asarray(psi)
+    amp = np.asarray(tensor.host_current(psi))
     keep = ((np.arange(amp.shape[0]) >> bit) & 1) == (1 if tostate else 0)
     prob = float(np.real(np.vdot(amp[keep], amp[keep])))
     if not collapse:

@@ -9,6 +9,8 @@ import cmath
 import math
 import os
 import random
+import sys
+import weakref
 
 import numpy as np
 
@@ -27,9 +29,12 @@ from qcc_amd.lib import tensor
 # attribute or method other than the handful that do not expose data.  After such a look the host buffer is the truth
 # again (the caller may have written to it): the next apply call uploads anew.  States below QCC_STATE_MIRROR_MIN_QUBITS
 # (default 18: 4 MiB, where PCIe stops mattering) and every State while a test has installed its own host executor keep
-# the literal per-call path; QCC_STATE_MIRROR_MIN_QUBITS=0 switches the mirror off.  What cannot be intercepted is a C
-# extension that was handed the array BEFORE the gates and reads its memory afterwards without going through Python
-# (np.asarray(psi) taken earlier and kept): such callers want the literal drop-in (qcc_amd.dropin.libxgates).
+# the literal per-call path; QCC_STATE_MIRROR_MIN_QUBITS=0 switches the mirror off.  Other State objects over the same memory
+# (a slice taken before the gates, the array a slice was taken from) are covered: mirrors are registered by the bytes they
+# stand for (_LIVE).  What no hook can intercept is C code reading the memory directly -- np.asarray(psi) / np.array(psi) do
+# not consult an ndarray subclass, an extension may have kept a pointer --: while the device is ahead the host bytes are
+# NaN, so such a read fails loudly instead of returning the state without its gates; look at the State itself (psi[:],
+# any NumPy function or method) or use the literal drop-in (qcc_amd.dropin.libxgates) for such callers.
 _mirror_totals = {'uploads': 0, 'downloads': 0, 'h2d_bytes': 0, 'd2h_bytes': 0, 'gates': 0}
 
 
@@ -47,16 +52,40 @@ def _mirror_min_qubits():
 
 
 class _Mirror:
-    __slots__ = ('dev', 'ahead')
+    __slots__ = ('dev', 'ahead', 'lo', 'hi', 'owner')
 
-    def __init__(self, dev):
+    def __init__(self, dev, lo, hi, owner):
         self.dev = dev          # the device state (qcc_amd.device.DeviceState or a substitute with its interface)
         self.ahead = False      # the device holds gates the host buffer has not seen
+        self.lo, self.hi = lo, hi       # the bytes of host memory this mirror stands for
+        self.owner = owner      # weakref to the State that holds it
+
+
+# Mirrors alive right now, by id(mirror).  A State is an ndarray: other State objects may be views of the same memory (a slice
+# taken before the gates, the array a slice was taken from).  Whoever looks at memory a live mirror stands for brings that
+# mirror home first, whichever object holds it: _sync_host checks this registry (empty almost always: one dict test per look).
+_LIVE = {}
+
+
+def _byte_range(arr):
+    from numpy.lib.array_utils import byte_bounds
+    return byte_bounds(np.ndarray.view(arr, np.ndarray))
+
+
+def _sync_overlapping(arr):
+    lo, hi = _byte_range(arr)
+    for m in list(_LIVE.values()):
+        if m.lo < hi and lo < m.hi:
+            owner = m.owner()
+            if owner is not None:
+                owner._sync_host()
+            else:
+                _LIVE.pop(id(m), None)
 
 
 _SAFE_ATTRS = frozenset((
     'apply1', 'applyc', 'nbits', 'shape', 'dtype', 'ndim', 'size', 'itemsize', 'nbytes', 'flags', 'strides', 'name', 'basis_index',
-    '_mirror', '_exec_buffer', '_sync_host', '_mirror_apply', '__class__', '__dict__', '__array_finalize__', '__array_priority__',
+    '_mirror', '_exec_buffer', '_sync_host', '_mirror_apply', 'base', '__class__', '__dict__', '__array_finalize__', '__array_priority__',
     '__del__', '__init__', '__new__', '__weakref__', '__doc__', '__module__', '__slots__'))
 
 
@@ -74,8 +103,11 @@ class State(tensor.Tensor):
         d = object.__getattribute__(self, '__dict__')
         m = d.get('_mirror')
         if m is None:
+            if _LIVE:
+                _sync_overlapping(self)
             return
         d['_mirror'] = None
+        _LIVE.pop(id(m), None)
         try:
             if m.ahead:
                 buf = np.ndarray.view(self, np.ndarray)
@@ -88,15 +120,23 @@ class State(tensor.Tensor):
     def __getattribute__(self, name):
         if name not in _SAFE_ATTRS:
             d = object.__getattribute__(self, '__dict__')
-            if d.get('_mirror') is not None:
+            if d.get('_mirror') is not None or _LIVE:
                 object.__getattribute__(self, '_sync_host')()
         return object.__getattribute__(self, name)
 
     def __del__(self):
         d = object.__getattribute__(self, '__dict__')
         m = d.get('_mirror')
+        if m is not None and m.ahead:
+            # gates pending: if anybody else can still reach the memory (the array a view was taken from, another view),
+            # they go home now; the sole holder of its buffer takes them to the grave -- no download
+            owner = np.ndarray.view(self, np.ndarray).base
+            if owner is not None and sys.getrefcount(owner) > 3:
+                object.__getattribute__(self, '_sync_host')()
+                m = None
         if m is not None:          # nobody can look any more: no download
             d['_mirror'] = None
+            _LIVE.pop(id(m), None)
             try:
                 backend.release_device_state(m.dev)
             except Exception:  # pylint: disable=broad-except
@@ -244,6 +284,8 @@ class State(tensor.Tensor):
             if lo <= 0 or n < lo or not backend.state_mirror_allowed():
                 return False
             buf = self._exec_buffer()
+            if _LIVE:
+                _sync_overlapping(self)     # (another State over the same memory holds a mirror: one mirror per byte)
             dev = backend.acquire_device_state(n, width)
             try:
                 dev.upload(buf)
@@ -252,7 +294,13 @@ class State(tensor.Tensor):
                 raise
             _mirror_totals['uploads'] += 1
             _mirror_totals['h2d_bytes'] += buf.nbytes
-            m = d['_mirror'] = _Mirror(dev)
+            # While the device is ahead the host bytes are POISON (NaN), not the old amplitudes: what no Python hook can see
+            # -- np.asarray(psi) / np.array(psi) hand the memory out in C without asking the subclass, and so does any
+            # extension that kept a pointer -- then reads NaN, loudly, instead of a plausible state that lacks the gates.
+            buf.view(np.float64 if buf.dtype == np.complex128 else np.float32).fill(np.nan)
+            lo_b, hi_b = _byte_range(self)
+            m = d['_mirror'] = _Mirror(dev, lo_b, hi_b, weakref.ref(self))
+            _LIVE[id(m)] = m
         g = np.asarray(gate).reshape(4)
         if control is None:
             m.dev.apply1(g, target)

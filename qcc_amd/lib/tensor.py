@@ -50,11 +50,21 @@ def tensor_type():
     return np.complex128 if width == 128 else np.complex64
 
 
+def host_current(x):
+    """x, with its host memory current: a State whose gates still sit on its device mirror (qcc_amd/lib/state.py) brings
+    them home.  np.asarray / np.array hand an ndarray subclass's memory out without asking it, so the library calls this
+    wherever it takes an array apart in that way."""
+    sync = getattr(x, '_sync_host', None)
+    if sync is not None:
+        sync()
+    return x
+
+
 class Tensor(np.ndarray):
     """A NumPy array with quantum-flavoured helpers; ``*`` is the Kronecker product."""
 
     def __new__(cls, input_array, op_name=None):
-        obj = np.asarray(input_array, dtype=tensor_type()).view(cls)
+        obj = np.asarray(host_current(input_array), dtype=tensor_type()).view(cls)
         obj.name = op_name
         return obj
 

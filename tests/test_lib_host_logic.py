@@ -458,8 +458,26 @@ def test_state_mirror_moves_the_state_twice_for_a_run_of_gates(monkeypatch):
     assert st['downloads'] == 1 and st['d2h_bytes'] == 16 << 8 and st['gates'] == 54
     v = psi[4:20]                                                    # a view has no mirror of its own
     assert v._mirror is None
+    # ... but it shares the memory: a view taken BEFORE the gates sees them (the reference's arrays alias), whichever object
+    # holds the mirror -- and the array a view was taken from sees the gates applied THROUGH the view
+    before = np.array(v)
+    psi.apply1(ops.PauliX(), 7)                                      # (qubit 7 = index bit 0: swaps neighbours)
+    o.apply1(ref, np.asarray(ops.PauliX()).reshape(4), 8, 7)
+    assert np.isnan(np.asarray(v)).all()                             # what bypasses the hooks reads poison, not a stale state
+    assert np.allclose(v[:], ref[4:20], atol=1e-12) and not np.allclose(v[:], before)
+    low = psi[0:128]                                                 # a 7-qubit State over the lower half
+    low.apply1(ops.Hadamard(), 0)
+    o.apply1(ref[0:128], np.asarray(ops.Hadamard()).reshape(4), 7, 0)
+    assert np.allclose(psi[:], ref, atol=1e-12)
+    low.apply1(ops.PauliX(), 2)
+    o.apply1(ref[0:128], np.asarray(ops.PauliX()).reshape(4), 7, 2)
+    del low                                                          # the view dies with a gate pending: its parent still sees it
+    assert np.allclose(psi[:], ref, atol=1e-12)
+    n_down = state.mirror_stats()['downloads']
+    n_up = state.mirror_stats()['uploads']
+    del v, before
     psi.apply1(ops.Hadamard(), 0)
-    del psi                                                          # dies with a gate pending: no download
-    assert state.mirror_stats()['downloads'] == 1 and state.mirror_stats()['uploads'] == 2
+    del psi                                                          # the sole holder dies with a gate pending: no download
+    assert state.mirror_stats()['downloads'] == n_down and state.mirror_stats()['uploads'] == n_up + 1
   finally:
     backend.set_state_mirror(None)
