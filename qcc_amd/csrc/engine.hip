@@ -1220,7 +1220,8 @@ __global__ __launch_bounds__(256) void k_tmax_collect(const uint64_t *__restrict
     }
 }
 // one block per collected unit: the smallest logical index among its amplitudes with probability == want
-__global__ __launch_bounds__(256) void k_tmax_scan(const double2 *__restrict__ psi, const unsigned long long *__restrict__ ids, qh::BitIns ins,
+template <typename A>
+__global__ __launch_bounds__(256) void k_tmax_scan(const A *__restrict__ psi, const unsigned long long *__restrict__ ids, qh::BitIns ins,
                                                     uint64_t tile_mask, int tile_bits, double want, BitMap bm, unsigned long long *out) {
   const uint64_t base = qh::expand_index(ids[1 + blockIdx.x], ins);
   unsigned long long best = ~0ull;
@@ -1237,7 +1238,8 @@ __global__ __launch_bounds__(256) void k_tmax_scan(const double2 *__restrict__ p
 }
 
 // the smallest logical index in [l0, l1) whose amplitude has probability == want (l2p: logical -> physical)
-__global__ __launch_bounds__(256) void k_prefix_scan(const double2 *__restrict__ psi, uint64_t l0, uint64_t l1, double want, BitMap l2p,
+template <typename A>
+__global__ __launch_bounds__(256) void k_prefix_scan(const A *__restrict__ psi, uint64_t l0, uint64_t l1, double want, BitMap l2p,
                                                       unsigned long long *out) {
   unsigned long long best = ~0ull;
   for (uint64_t l = l0 + (uint64_t)blockIdx.x * 256 + threadIdx.x; l < l1; l += (uint64_t)gridDim.x * 256)
@@ -1278,7 +1280,10 @@ int argmax_from_tilemax(qh_state_s *h, const qh::TileMaxOut &tm, const BitMap &b
     uint64_t l0 = 0;
     for (uint64_t l1 = std::min<uint64_t>(n, 1ull << 16); l0 < n; l0 = l1, l1 = std::min<uint64_t>(n, l1 << 6)) {
       const unsigned g = (unsigned)std::min<uint64_t>((l1 - l0 + 255) / 256, 1u << 16);
-      hipLaunchKernelGGL(k_prefix_scan, dim3(g), dim3(256), 0, h->stream, (const double2 *)h->d_psi, l0, l1, want, l2p, ids + 1 + kTmaxIds);
+      if (h->bw == 128)
+        hipLaunchKernelGGL(k_prefix_scan<double2>, dim3(g), dim3(256), 0, h->stream, (const double2 *)h->d_psi, l0, l1, want, l2p, ids + 1 + kTmaxIds);
+      else
+        hipLaunchKernelGGL(k_prefix_scan<float2>, dim3(g), dim3(256), 0, h->stream, (const float2 *)h->d_psi, l0, l1, want, l2p, ids + 1 + kTmaxIds);
       unsigned long long hit = ~0ull;
       HIP_TRY(hipMemcpyAsync(&hit, ids + 1 + kTmaxIds, 8, hipMemcpyDeviceToHost, h->stream));
       if ((rc = wait_stream(h, h->stream, "reader"))) return rc;
@@ -1291,8 +1296,12 @@ int argmax_from_tilemax(qh_state_s *h, const qh::TileMaxOut &tm, const BitMap &b
     }
     return QH_OK;      // (cannot happen)
   }
-  hipLaunchKernelGGL(k_tmax_scan, dim3((unsigned)cnt), dim3(256), 0, h->stream, (const double2 *)h->d_psi, ids, tm.ins, tm.tile_mask,
-                     __builtin_popcountll(tm.tile_mask), want, bm, ids + 1 + kTmaxIds);
+  if (h->bw == 128)
+    hipLaunchKernelGGL(k_tmax_scan<double2>, dim3((unsigned)cnt), dim3(256), 0, h->stream, (const double2 *)h->d_psi, ids, tm.ins, tm.tile_mask,
+                       __builtin_popcountll(tm.tile_mask), want, bm, ids + 1 + kTmaxIds);
+  else
+    hipLaunchKernelGGL(k_tmax_scan<float2>, dim3((unsigned)cnt), dim3(256), 0, h->stream, (const float2 *)h->d_psi, ids, tm.ins, tm.tile_mask,
+                       __builtin_popcountll(tm.tile_mask), want, bm, ids + 1 + kTmaxIds);
   unsigned long long li = ~0ull;
   HIP_TRY(hipMemcpyAsync(&li, ids + 1 + kTmaxIds, 8, hipMemcpyDeviceToHost, h->stream));
   if ((rc = wait_stream(h, h->stream, "reader"))) return rc;
@@ -1307,9 +1316,9 @@ int argmax_from_tilemax(qh_state_s *h, const qh::TileMaxOut &tm, const BitMap &b
 extern "C" int qh_argmax(qh_handle h, uint64_t *phys_index, double *prob) {
   if (!h || !phys_index || !prob || h->dry) return fail(QH_ERR_ARG, "null/dry");
   HIP_TRY(hipSetDevice(h->device));
-  // the flush in front of the reader: its last sweep may leave the maximum of every unit it stores (complex128, no communicator)
+  // the flush in front of the reader: its last sweep may leave the maximum of every unit it stores (no communicator)
   qh::TileMaxOut tm;
-  if (h->fusion == QH_FUSE_SWEEP && h->bw == 128 && !h->comm && !h->queue.empty() && qh::sweep_supported(h->nloc, h->bw) &&
+  if (h->fusion == QH_FUSE_SWEEP && !h->comm && !h->queue.empty() && qh::sweep_supported(h->nloc, h->bw) &&
       env_int("QH_FUSED_ARGMAX", 1) != 0) {
     const uint64_t need = 1ull << (h->nloc - qh::kLaneBits - 3);       // units of a three-register-bit tile (a sweep without dense gates); plans
                                                                        // with dense gates use five: a flush that wants more entries takes the full pass
