@@ -2,7 +2,7 @@
  * libq.h -- `libq`-compatible C++ facade over the MI355X engine.
  *
  * Same namespace, type names and function signatures as the reference's
- * src/libq/libq.h:44-69, so a program transpiled by qcc (`--libq=prog.cc`,
+ * src/libq/libq.h:44-69 (libq_gate1 included), so a program transpiled by qcc (`--libq=prog.cc`,
  * src/lib/dumpers.py:40-86) compiles against this header instead and runs on the
  * GPU:   hipcc prog.cc -I<repo>/include <repo>/qcc_amd/csrc/libq_facade.cc \
  *              -L<repo>/qcc_amd -lqcc_hip -Wl,-rpath,<repo>/qcc_amd
@@ -63,7 +63,13 @@ void cu1(int control, int target, float gamma, qureg *reg);
 void cv(int control, int target, qureg *reg);
 void cv_adj(int control, int target, qureg *reg);
 
+/* -- the reference's "Internal" section (src/libq/libq.h:66-69), public in its header and the entry every dense gate of
+ *    src/libq/gates.cc goes through (gates.cc:13,44,52,102,114; body src/libq/apply.cc:78-176) ------------------------- */
 float probability(cmplx ampl);
+/* amplitude pair (bit `target` = 0, 1) <- [[m[0], m[1]], [m[2], m[3]]] x pair, for every pair of the register
+ * (apply.cc:119-137); m need not be unitary.  Dense here: no hash table, no pruning of small amplitudes
+ * (apply.cc:149-171 drops what falls below 1e-6 / 2^width -- print_qureg applies that limit when it lists). */
+void libq_gate1(int target, cmplx m[4], qureg *reg);
 
 }  // namespace libq
 

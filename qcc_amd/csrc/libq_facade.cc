@@ -59,6 +59,16 @@ template <typename F> int visit(qureg *reg, F f) {
 
 float probability(cmplx a) { return a.real() * a.real() + a.imag() * a.imag(); }
 
+// src/libq/libq.h:69, apply.cc:78-176: an arbitrary 2x2 on index bit `target` (libq's bit order), row-major m
+void libq_gate1(int target, cmplx m[4], qureg *reg) {
+  double g[8];
+  for (int k = 0; k < 4; ++k) {
+    g[2 * k] = m[k].real();
+    g[2 * k + 1] = m[k].imag();
+  }
+  gate(reg, 0, target, g);
+}
+
 qureg *new_qureg(state_t initval, int width) {
   qureg *reg = new qureg;
   reg->width = width;

@@ -9,7 +9,8 @@
 // and the two dense vectors are compared.
 //
 // Input (text file argv[1]):   ncases, then per case  "width initval nops"  and nops lines
-//   "name a b c gamma"  (unused arguments are 0).  Output (binary file argv[2]): per case
+//   "name a b c gamma"  (unused arguments are 0; "gate1 target 0 0 0" is followed by the eight numbers re im of m[0..3] and
+//   goes to libq::libq_gate1, src/libq/libq.h:69).  Output (binary file argv[2]): per case
 //   2^width complex<double>, index = libq basis state.
 #include <complex>
 #include <cstdio>
@@ -65,6 +66,15 @@ int main(int argc, char **argv) {
       int a, b, c;
       double gamma;
       if (fscanf(in, "%15s %d %d %d %lf", name, &a, &b, &c, &gamma) != 5) return 1;
+      if (!strcmp(name, "gate1")) {
+        double v[8];
+        for (double &x : v)
+          if (fscanf(in, "%lf", &x) != 1) return 1;
+        libq::cmplx m[4];
+        for (int k = 0; k < 4; ++k) m[k] = libq::cmplx((float)v[2 * k], (float)v[2 * k + 1]);
+        libq::libq_gate1(a, m, q);
+        continue;
+      }
       apply(name, a, b, c, gamma, q);
     }
     dump(q, out);

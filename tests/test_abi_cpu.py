@@ -152,7 +152,7 @@ def test_libq_facade_header_links(tmp_path, lib):
   text = re.sub(r'//.*', '', text)
   decl = re.findall(r'^\s*(?:void|qureg \*|float)\s*\*?(\w+)\s*\(([^)]*)\)\s*;', text, flags=re.M)
   names = [n for n, _ in decl]
-  assert {'new_qureg', 'print_qureg', 'h', 'cu1', 'ccx', 'cv_adj', 'flush'} <= set(names) and len(names) >= 20
+  assert {'new_qureg', 'print_qureg', 'h', 'cu1', 'ccx', 'cv_adj', 'flush', 'libq_gate1'} <= set(names) and len(names) >= 22
   body = '\n'.join(f'  (void)&libq::{n};' for n in names)
   # take the address of each function through a volatile sink so the linker must resolve it
   src = tmp_path / 'link_all.cc'

@@ -88,8 +88,9 @@ def _run_driver(exe, tmp_path, cases):
     f.write(f'{len(cases)}\n')
     for w, init, ops in cases:
       f.write(f'{w} {init} {len(ops)}\n')
-      for name, a, b, c, gamma in ops:
-        f.write(f'{name} {a} {b} {c} {gamma!r}\n')
+      for op in ops:
+        name, a, b, c, gamma = op[:5]
+        f.write(f'{name} {a} {b} {c} {gamma!r}' + ''.join(f' {float(x)!r}' for x in op[5:]) + '\n')   # gate1: + 8 numbers
   subprocess.check_call([str(exe), str(inp), str(outp)], stdout=subprocess.DEVNULL)
   raw = np.fromfile(outp, dtype=np.complex128)
   out, off = [], 0
@@ -158,3 +159,33 @@ def test_libq_root_gates_match_ops_matrices(oracle, tmp_path):
       else:
         oracle.applyc(psi, mats[name].reshape(4), w, a, b)
     assert np.max(np.abs(g - psi[rev])) < 1e-7, ops[-1]   # float angles in the u1 calls
+
+
+def test_libq_gate1_matches_oracle_and_reference_libq(oracle, golden_dir, tmp_path):
+  """SURVEY 8a row A6 (src/libq/libq.h:69, apply.cc:78-176): an arbitrary 2x2 through the libq boundary.  libq_gate1 of
+  include/libq.h on the GPU -- random unitaries, non-unitary matrices and H on EVERY target of dense 6-, 8- and 10-qubit
+  registers and of single basis states -- against the oracle at 1e-10 (same float matrix entries, complex128 arithmetic)
+  and against what the reference's own libq_gate1 computed for the identical calls (golden G10, complex<float>)."""
+  from tests.test_oracle_golden import libq_gate1_cases, libq_gate1_expected, libq_gate1_prep
+  cases = libq_gate1_cases(golden_dir)
+  progs = []
+  for w, init, dp, t, m, _ in cases:
+    nums = [float(x) for z in m for x in (z.real, z.imag)]
+    progs.append((w, init, (libq_gate1_prep(w) if dp else []) + [('gate1', t, 0, 0, 0.0, *nums)]))
+  # three more matrices the fixture does not hold, oracle only: a projector, a nilpotent matrix, a scaled rotation
+  extra = [np.array([1, 0, 0, 0], dtype=np.complex64), np.array([0, 1, 0, 0], dtype=np.complex64),
+           np.array([1.5, -0.5j, 0.5j, 1.5], dtype=np.complex64)]
+  extra_cases = []
+  for w in (6, 9):
+    for m in extra:
+      for t in range(w):
+        extra_cases.append((w, 5, 1, t, m))
+        nums = [float(x) for z in m for x in (z.real, z.imag)]
+        progs.append((w, 5, libq_gate1_prep(w) + [('gate1', t, 0, 0, 0.0, *nums)]))
+  got = _run_driver(_build_driver(tmp_path), tmp_path, progs)
+  for (w, init, dp, t, m, dense), g in zip(cases, got):
+    want = libq_gate1_expected(oracle, w, init, dp, t, m)
+    assert np.max(np.abs(g - want)) < 1e-10, (w, init, dp, t)
+    assert np.max(np.abs(g - dense)) < 3e-6 * max(1.0, float(np.max(np.abs(want)))), (w, init, dp, t)
+  for (w, init, dp, t, m), g in zip(extra_cases, got[len(cases):]):
+    assert np.max(np.abs(g - libq_gate1_expected(oracle, w, init, dp, t, m))) < 1e-10, (w, t, m)

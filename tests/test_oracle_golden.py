@@ -161,6 +161,64 @@ def test_reference_libq_gate_set_equals_dense_semantics(oracle, golden_dir):
   assert seen >= {'x', 'y', 'z', 'h', 't', 'u1', 'cu1', 'cx', 'cz', 'ccx', 'walsh'}
 
 
+def libq_gate1_prep(w):
+  """The libq calls that make the dense entangled register of the libq_gate1 cases (tools/make_golden_r6.py and
+  tests/test_gpu_libq_facade.py run exactly these in front of the gate)."""
+  return ([('walsh', w, 0, 0, 0.0)] + [('u1', i, 0, 0, 0.21 * (i + 1)) for i in range(w)]
+          + [('cu1', 0, w - 2, 0, 0.6), ('h', 2, 0, 0, 0.0), ('cx', 1, w - 1, 0, 0.0)])
+
+
+def libq_gate1_cases(golden_dir):
+  """Decodes g10_libq_gate1.npz: [(width, initval, dense_prep, target, m[4] complex64, dense complex64)]."""
+  g = _load(golden_dir, 'g10_libq_gate1.npz')
+  out, off = [], 0
+  for w, init, dp, t, m in zip(g['width'], g['init'], g['dense_prep'], g['target'], g['m']):
+    out.append((int(w), int(init), int(dp), int(t), m, g['dense'][off:off + (1 << int(w))]))
+    off += 1 << int(w)
+  assert off == g['dense'].size
+  return out
+
+
+def libq_gate1_expected(oracle, w, init, dense_prep, target, m):
+  """The dense 2x2 semantics of libq_gate1 through the oracle: libq target t = index bit t = reference qubit t of the
+  bit-reversed index; returns the state indexed by libq basis state."""
+  import cmath
+  s = 1 / np.sqrt(2)
+  psi = np.zeros(1 << w, dtype=np.complex128)
+  psi[int(format(init, f'0{w}b')[::-1], 2)] = 1
+  if dense_prep:
+    for name, a, b, _, gamma in libq_gate1_prep(w):
+      if name == 'walsh':
+        for i in range(a):
+          oracle.apply1(psi, np.array([s, s, s, -s], dtype=np.complex128), w, i)
+      elif name == 'h':
+        oracle.apply1(psi, np.array([s, s, s, -s], dtype=np.complex128), w, a)
+      elif name == 'u1':
+        oracle.apply1(psi, np.array([1, 0, 0, cmath.exp(1j * np.float32(gamma))]), w, a)
+      elif name == 'cu1':
+        oracle.applyc(psi, np.array([1, 0, 0, cmath.exp(1j * np.float32(gamma))]), w, a, b)
+      elif name == 'cx':
+        oracle.applyc(psi, np.array([0, 1, 1, 0], dtype=np.complex128), w, a, b)
+      else:
+        raise AssertionError(name)
+  oracle.apply1(psi, np.asarray(m, dtype=np.complex128), w, target)
+  rev = np.array([int(format(k, f'0{w}b')[::-1], 2) for k in range(1 << w)])
+  return psi[rev]
+
+
+def test_reference_libq_gate1_equals_dense_apply1(oracle, golden_dir):
+  """A6 (src/libq/libq.h:69, apply.cc:78-176): what the reference's own libq_gate1 computed for unitary and non-unitary
+  2x2 matrices on every target of 6-, 8- and 10-qubit registers (dense and single-basis-state inputs) equals apply1's
+  dense semantics with m row-major, to float accuracy.  Pins what the facade's libq_gate1 implements."""
+  cases = libq_gate1_cases(golden_dir)
+  assert len(cases) == 2 * 4 * (6 + 8 + 10)
+  assert {(c[0], c[3]) for c in cases} == {(w, t) for w in (6, 8, 10) for t in range(w)}
+  for w, init, dp, t, m, dense in cases:
+    want = libq_gate1_expected(oracle, w, init, dp, t, m)
+    scale = max(1.0, float(np.max(np.abs(want))))
+    assert np.max(np.abs(want - dense)) < 3e-6 * scale, (w, init, dp, t)
+
+
 def test_all_core_variant_equals_serial(golden_dir):
   """oracle_run_stream_c128_mt (the all-core CPU-baseline leg of bench.py) against the serial
   restatement on recorded reference traces and a random stream; serial and OpenMP builds."""
