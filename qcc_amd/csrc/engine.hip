@@ -1319,6 +1319,7 @@ extern "C" int qh_argmax(qh_handle h, uint64_t *phys_index, double *prob) {
   // the flush in front of the reader: its last sweep may leave the maximum of every unit it stores (no communicator)
   qh::TileMaxOut tm;
   if (h->fusion == QH_FUSE_SWEEP && !h->comm && !h->queue.empty() && qh::sweep_supported(h->nloc, h->bw) &&
+      h->nloc >= qh::kLaneBits + 3 &&      // (sweep_supported() admits nloc = kLaneBits + 2: no shift by a negative count below)
       env_int("QH_FUSED_ARGMAX", 1) != 0) {
     const uint64_t need = 1ull << (h->nloc - qh::kLaneBits - 3);       // units of a three-register-bit tile (a sweep without dense gates); plans
                                                                        // with dense gates use five: a flush that wants more entries takes the full pass
@@ -1326,8 +1327,8 @@ extern "C" int qh_argmax(qh_handle h, uint64_t *phys_index, double *prob) {
       if (h->d_tmax) (void)hipFree(h->d_tmax);
       h->d_tmax = nullptr;
       h->tmax_cap = 0;
-      if (hipMalloc((void **)&h->d_tmax, need * 8) == hipSuccess) h->tmax_cap = need;
-      else (void)hipGetLastError();
+      if (hipMalloc((void **)&h->d_tmax, need * 8) == hipSuccess && h->d_tmax) h->tmax_cap = need;
+      else { h->d_tmax = nullptr; (void)hipGetLastError(); }
     }
     tm.buf = h->d_tmax;
     tm.cap = h->tmax_cap;

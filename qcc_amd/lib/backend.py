@@ -174,18 +174,30 @@ def acquire_device_state(nbits, bit_width):
 _state_mirror_forced = None
 
 
+def state_mirror_setting():
+    return _state_mirror_forced
+
+
 def set_state_mirror(on):
-    """Test seam: True / False forces the State mirror on / off whatever executor is installed; None = the rule below."""
+    """Opt in (True) to / out (False) of device mirrors for States driven through State.apply1 / applyc directly
+    (qcc_amd/lib/state.py; `with state.device_mirror():` wraps this); None = the rule of state_mirror_allowed().  Switching
+    the mode off brings every live mirror home first."""
     global _state_mirror_forced
     _state_mirror_forced = on
+    if not state_mirror_allowed():
+        from qcc_amd.lib import state
+        state.sync_all_mirrors()
 
 
 def state_mirror_allowed():
-    """State.apply1 / applyc may keep a device mirror only while the default host executor is in place (a test that
-    installed its own executor wants to see every call) and the process is not one rank of a sharded job."""
+    """State.apply1 / applyc keep the literal per-call path (the reference's contract: the host array holds the result when
+    the call returns) unless the caller opted in: set_state_mirror(True) / state.device_mirror(), or QCC_STATE_MIRROR=1 in
+    the environment -- the latter only while the default host executor is in place (a test that installed its own executor
+    wants to see every call) and the process is not one rank of a sharded job."""
     if _state_mirror_forced is not None:
         return bool(_state_mirror_forced)
-    return ((_host_executor is None or type(_host_executor) is HipHostExecutor)  # pylint: disable=unidiomatic-typecheck
+    return (os.environ.get('QCC_STATE_MIRROR', '0') == '1'
+            and (_host_executor is None or type(_host_executor) is HipHostExecutor)  # pylint: disable=unidiomatic-typecheck
             and int(os.environ.get('WORLD_SIZE', '1')) == 1)
 
 

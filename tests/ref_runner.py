@@ -70,6 +70,12 @@ def main():
     # plan: gates go through the engine's planner; the plan is executed with NumPy (no GPU)
     backend.set_device_factory(fake_device.PlanDevice if mode == 'plan' else fake_device.OracleDevice)
     backend.set_host_executor(fake_device.OracleHostExecutor())
+  if os.environ.get('QCC_TEST_STATE_MIRROR') == '1':
+    # the opt-in device mirror of directly driven States (qcc_amd/lib/state.py), on for every State of the run
+    backend.set_state_mirror(True)
+    import atexit
+    from qcc_amd.lib import state as _st
+    atexit.register(lambda: print('state-mirror:', _st.mirror_stats(), file=sys.stderr))
   # algorithms import helpers as `from src.lib import ...` (ours) and each other as
   # `from src import x`: expose the reference's src/ directory for the latter only.
   import src

@@ -105,6 +105,16 @@ def test_state_methods_through_the_device_mirror(golden_dir, oracle, monkeypatch
   sweeps, one download at the first look) -- VERDICT r04 #6: 40 direct calls on a 24-qubit State move <= 2 x S over PCIe,
   the amplitudes equal the oracle's; the reference's own recorded fallback sequence (py_fallback.npz, negative controls
   included) gives the golden result through the mirror as well."""
+  from qcc_amd.lib import backend
+  assert not backend.state_mirror_allowed()               # opt-in (ADVICE r05): the default is the literal per-call path
+  backend.set_state_mirror(True)
+  try:
+    _state_methods_through_the_device_mirror(golden_dir, oracle, monkeypatch)
+  finally:
+    backend.set_state_mirror(None)
+
+
+def _state_methods_through_the_device_mirror(golden_dir, oracle, monkeypatch):
   state.mirror_stats(reset=True)
   n = 24
   rng = np.random.default_rng(11)

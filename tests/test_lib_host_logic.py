@@ -435,7 +435,7 @@ def test_state_mirror_keeps_the_host_contract(monkeypatch):
 
 def test_state_mirror_moves_the_state_twice_for_a_run_of_gates(monkeypatch):
   """40 direct apply calls = one upload + one download, views and copies never share a mirror, a State
-  that dies with gates pending downloads nothing."""
+  that owns its buffer and dies with gates pending downloads nothing, one that aliases somebody's array brings them home."""
   monkeypatch.setenv('QCC_STATE_MIRROR_MIN_QUBITS', '3')
   backend.set_state_mirror(True)
   try:
@@ -476,8 +476,68 @@ def test_state_mirror_moves_the_state_twice_for_a_run_of_gates(monkeypatch):
     n_down = state.mirror_stats()['downloads']
     n_up = state.mirror_stats()['uploads']
     del v, before
+    # a State made from an array ALIASES it (State(a) is a view of a): when it dies with a gate pending the gates go home,
+    # unconditionally (no reference-count guessing) -- whoever holds `a` sees them
     psi.apply1(ops.Hadamard(), 0)
-    del psi                                                          # the sole holder dies with a gate pending: no download
-    assert state.mirror_stats()['downloads'] == n_down and state.mirror_stats()['uploads'] == n_up + 1
+    o.apply1(ref, np.asarray(ops.Hadamard()).reshape(4), 8, 0)
+    raw = psi.base
+    assert raw is not None and type(raw) is np.ndarray
+    del psi
+    assert state.mirror_stats()['downloads'] == n_down + 1 and state.mirror_stats()['uploads'] == n_up + 1
+    assert np.allclose(raw, ref, atol=1e-12)
+    # only a State that OWNS its buffer (no base: nobody else can reach the memory once it is gone) dies without a download
+    own = state.State(ref).copy()
+    assert own.base is None
+    own.apply1(ops.Hadamard(), 3)
+    del own
+    assert state.mirror_stats()['downloads'] == n_down + 1 and state.mirror_stats()['uploads'] == n_up + 2
   finally:
     backend.set_state_mirror(None)
+
+
+def test_state_mirror_is_opt_in_and_costs_nothing_when_off(monkeypatch):
+  """the device mirror is OFF unless the caller opts in -- the default keeps the reference's literal contract
+  (the host array holds the result when apply1 returns: state.py:80-125) --, a State carries no Python-level hooks until
+  the first mirror is made and loses them again when the mode is off and the last mirror has gone home, leaving a
+  `with state.device_mirror()` block brings every mirror home, a user subclass of State goes through the ufunc hook
+  without recursing, and the byte range of an array does not need NumPy >= 2."""
+  monkeypatch.setenv('QCC_STATE_MIRROR_MIN_QUBITS', '3')
+  monkeypatch.delenv('QCC_STATE_MIRROR', raising=False)
+  assert backend.state_mirror_setting() is None and not backend.state_mirror_allowed()
+  hooks = ('__getattribute__', '__getitem__', '__array_ufunc__', '__array_function__', '__del__', '__repr__')
+  assert not any(h in state.State.__dict__ for h in hooks)
+  state.mirror_stats(reset=True)
+  a = np.zeros(1 << 6, dtype=np.complex128)
+  a[0] = 1
+  psi = state.State(a)                       # aliases a
+  psi.apply1(ops.Hadamard(), 0)
+  assert state.mirror_stats()['gates'] == 0 and abs(a[0] - 2 ** -0.5) < 1e-12 and abs(a[32] - 2 ** -0.5) < 1e-12
+  assert not any(h in state.State.__dict__ for h in hooks)
+
+  class MyState(state.State):
+    pass
+
+  with state.device_mirror():
+    assert backend.state_mirror_allowed()
+    psi.apply1(ops.Hadamard(), 1)
+    assert all(h in state.State.__dict__ for h in hooks)
+    assert state.mirror_stats()['gates'] == 1 and np.isnan(a).all()       # raw memory: poison (silent), documented
+    mine = np.ndarray.view(state.State(np.ones(1 << 6, dtype=np.complex128)), MyState)
+    mine.apply1(ops.PauliX(), 2)
+    assert type(mine + mine) is MyState and np.allclose(np.asarray((mine + mine)[:]), 2.0)     # no recursion
+    assert type(np.add(mine, 1.0, out=mine)) is MyState
+  # the block has ended: everything is home, the raw array the State was made from holds the result, hooks are gone
+  assert not backend.state_mirror_allowed() and not state._LIVE
+  assert abs(a[0] - 0.5) < 1e-12 and abs(a[16] - 0.5) < 1e-12 and abs(a[32] - 0.5) < 1e-12 and abs(a[48] - 0.5) < 1e-12
+  assert not any(h in state.State.__dict__ for h in hooks)
+  assert state.mirror_stats()['downloads'] >= 1
+  # QCC_STATE_MIRROR=1 opts in from the environment -- but never while a test executor is installed
+  monkeypatch.setenv('QCC_STATE_MIRROR', '1')
+  assert not backend.state_mirror_allowed()
+  # byte range without numpy.lib.array_utils (NumPy 1.x without byte_bounds either)
+  monkeypatch.setattr(state, '_byte_bounds', None)
+  x = np.arange(40, dtype=np.complex128)
+  lo = x.__array_interface__['data'][0]
+  assert state._byte_range(x) == (lo, lo + 640)
+  assert state._byte_range(x[4:20:3]) == (lo + 64, lo + 64 + 15 * 16 + 16)
+  assert state._byte_range(x[::-1]) == (lo, lo + 640)

@@ -68,3 +68,19 @@ def test_reference_code_through_the_planner(name):
 
 def test_complex128_width_on_api_mirror():
   _run(os.path.join(REF, 'lib', 'circuit_test.py'), 'cpu', env={'QCC_TENSOR_WIDTH': '128'})
+
+
+@pytest.mark.parametrize('name', ['lib/state_test', 'lib/circuit_test', 'lib/measure_test', 'grover', 'counting', 'sat3',
+                                  'minimum_finding', 'state_prep'])
+def test_reference_code_with_the_state_mirror_on(name):
+  """the reference's own State tests and its five direct callers of State.apply1 / applyc (grover.py:77,
+  counting.py:54, sat3.py:129, minimum_finding.py:88, state_prep.py:53) with the opt-in device mirror of
+  qcc_amd/lib/state.py switched ON for every State, however small (QCC_STATE_MIRROR_MIN_QUBITS=1): every look the
+  reference's code takes at a State -- indexing, NumPy calls, prints, comparisons -- must see the gates."""
+  r = _run(os.path.join(REF, name + '.py'), 'cpu', env={'QCC_TEST_STATE_MIRROR': '1', 'QCC_STATE_MIRROR_MIN_QUBITS': '1'})
+  if name.startswith('lib/'):
+    assert 'OK' in r.stderr
+  import ast
+  stats = ast.literal_eval(r.stderr.rsplit('state-mirror:', 1)[1].strip().splitlines()[0])
+  if name not in ('lib/measure_test', 'lib/state_test'):   # (the other six drive a State directly: the mirror must have engaged)
+    assert stats['gates'] > 0 and stats['uploads'] > 0 and stats['downloads'] > 0, stats
