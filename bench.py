@@ -55,6 +55,8 @@ def parse():
   ap.add_argument('--fusion', type=int, default=-1, help='0 per-gate kernels, 1 fused sweeps (default)')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-cached-plan', action='store_true', help='skip the extra steps timed with the plan cache on')
+  ap.add_argument('--no-live-traffic', action='store_true',
+                  help='N=1: do not measure roofline.traffic with rocprofv3 in this run (the committed profile is quoted instead)')
   ap.add_argument('--sharded', action='store_true', help='use the multi-GPU layer even with one rank (smoke)')
   ap.add_argument('--cpu-qubits', type=int, default=30)
   ap.add_argument('--cpu-gates', type=int, default=14, help='gates of the stream timed on the CPU')
@@ -109,6 +111,49 @@ def pmc_traffic(kernel_substr, fused, name=None):
   if best is None:
     return None, None
   return best['hbm_bytes'], os.path.relpath(files[-1], ROOT)
+
+
+def live_traffic(workload='qft30', reps=2, timeout_s=150):
+  """HBM bytes per k_sweep launch MEASURED IN THIS RUN: two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; with
+  --kernel-trace only, as MI355X_MICROARCH.md's HBM section prescribes: counters in KiB, FETCH_SIZE doubled on gfx950 for
+  16-B-per-lane streaming reads) over tools/run_workload.py <workload> in a child process.  Returns (bytes, source) or
+  (None, why) -- no rocprofv3 on the box, already running under a profiler, a pass that fails or times out: the caller then
+  falls back to the committed profile and says so."""
+  import csv
+  import glob
+  import shutil
+  import subprocess
+  import tempfile
+  exe = shutil.which('rocprofv3')
+  if exe is None:
+    return None, 'rocprofv3 not on PATH'
+  if any(k.startswith(('ROCPROFILER_', 'ROCPROF_', 'ROCP_TOOL')) for k in os.environ):
+    return None, 'already running under a profiler'
+  med = {}
+  tmp = tempfile.mkdtemp(prefix='qcc_pmc_', dir='/tmp')
+  try:
+    for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
+      d = os.path.join(tmp, ctr)
+      env = dict(os.environ, TMPDIR='/tmp')
+      r = subprocess.run([exe, '--kernel-trace', '--pmc', ctr, '--output-format', 'csv', '-d', d, '-o', 'p', '--', sys.executable,
+                          os.path.join(ROOT, 'tools', 'run_workload.py'), workload, str(reps)], cwd='/tmp', env=env,
+                         capture_output=True, text=True, timeout=timeout_s)
+      files = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)
+      if r.returncode != 0 or not files:
+        return None, f'rocprofv3 --pmc {ctr} failed (rc {r.returncode})'
+      vals = [float(row['Counter_Value']) for row in csv.DictReader(open(files[0]))
+              if 'k_sweep' in row['Kernel_Name'] and row['Counter_Name'] == ctr]
+      if not vals:
+        return None, f'no k_sweep dispatch in the {ctr} pass'
+      vals.sort()
+      med[ctr] = vals[len(vals) // 2]
+    return (2 * med['FETCH_SIZE'] + med['WRITE_SIZE']) * 1024, ('measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE '
+                                                               f'(separate passes) over tools/run_workload.py {workload} {reps}; '
+                                                               '(2 x FETCH_SIZE + WRITE_SIZE) x 1024, median over the k_sweep dispatches')
+  except Exception as e:  # pylint: disable=broad-except
+    return None, f'{type(e).__name__}: {e}'
+  finally:
+    shutil.rmtree(tmp, ignore_errors=True)
 
 
 def cpu_baseline(args, ops, g8):
@@ -341,6 +386,11 @@ def other_configs(device_index):
   out['config3_supremacy30_d20_seed0'] = config_line(
       '30-qubit supremacy.py random circuit, depth 20, random.seed(0) [BASELINE config 3]', 30, 128, ops, g8, 0, device_index, 5, 2,
       'op-heavy sweeps: bound by the socket power limit, not by HBM -- op streams alone 1 284 W at 2.39 GHz, with the tile streams 1 391 W of 1 400 W at 1.92 GHz (DESIGN 4.5, profiles/r04/smi_trace_sup30_*.csv)', 'traffic_sup30.json')
+  for seed in (1, 2):          # SURVEY 8(d) config 3 names seeds 0, 1, 2
+    ops, g8 = workloads.supremacy_stream(30, 20, seed=seed).arrays()
+    out[f'config3_supremacy30_d20_seed{seed}'] = config_line(
+        f'30-qubit supremacy.py random circuit, depth 20, random.seed({seed}) [BASELINE config 3, SURVEY 8(d) seeds 0-2]', 30, 128, ops, g8, 0,
+        device_index, 5, 2, 'same family as seed 0; the number of sweeps depends on the instance (DESIGN 4.4 tile search)')
   ops, g8 = workloads.qft_stream(range(30)).arrays()
   out['qft30_complex64'] = config_line(
       '30-qubit QFT at the reference\'s default width complex64 (src/lib/tensor.py:28)', 30, 64, ops, g8,
@@ -523,8 +573,10 @@ def main():
         other = {}
       achieved = bytes_l / (ms_l * 1e-3) / 1e9
       traffic, tsrc = pmc_traffic(name.split(' ')[0], fusion != native.QH_FUSE_OFF)
+      traffic_profile = {'bytes': traffic, 'source': tsrc}
       roofline = {'bound': 'hbm', 'kernel': name, 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                   'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic, 'traffic_source': tsrc,
+                  'traffic_from_profile': traffic_profile,
                   'avg_launch_ms': ms_l, 'bytes_per_launch': bytes_l, 'classes': other}
     else:
       roofline = {'bound': 'hbm', 'achieved': stats['bytes_swept'] / (ev_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBPS,
@@ -553,6 +605,12 @@ def main():
     if cached:
       out['cached_plan'] = cached
     if dist is not None:
+      from qcc_amd import sharded as _sh
+      # what this step SHOULD cost (sweeps at the measured single-GPU rate + the exchange over the links with the
+      # overlap the slabs allow), from the sweep / exchange counts this run actually had -- beside the measurement
+      out['predicted_ms_per_step'] = _sh.predict_step_ms(n, world, sweeps=stats['sweeps'] / steps,
+                                                         exchanges=stats.get('exchanges', 0) / steps)
+      out['memory_plan'] = getattr(eng, 'memory_plan', None)
       out['exchanges_per_step'] = stats.get('exchanges', 0) / steps
       out['xgmi_bytes_per_rank_per_step'] = stats.get('exchanged_bytes', 0) / steps
       out['exchange_ms_per_step_rank0'] = stats.get('exchange_seconds', 0.0) / steps * 1e3
@@ -573,6 +631,14 @@ def main():
     eng.close()
   if rank == 0:
     extras = world == 1 and dist is None and n == 30 and fusion != native.QH_FUSE_OFF
+    if extras and not args.no_live_traffic:
+      # roofline.traffic measured in THIS run (VERDICT r05 "what's weak" 8): the engine is closed, a child process runs the
+      # same 30-qubit QFT under rocprofv3's PMC passes; the committed profile's figure stays beside it as traffic_from_profile
+      t_live, why = live_traffic('qft30')
+      if t_live is not None:
+        out['roofline']['traffic'], out['roofline']['traffic_source'] = t_live, why
+      else:
+        out['roofline']['traffic_source'] = f"{out['roofline']['traffic_source']} (committed profile; live measurement unavailable: {why})"
     if extras and not args.no_configs:
       # before the 128- and 256-GiB states below: the allocation that follows the release of such a state pays ~6 s of driver
       # work deferred from the release (profiles/r05/alloc_second_buffer_ab.txt) -- rounds 4 and 5 reported it as this entry's
@@ -584,7 +650,7 @@ def main():
       out['configs'] = other_configs(local_rank)
     if not args.no_cpu_baseline and world == 1:
       out['cpu_baseline'] = cpu_baseline(args, ops, g8)
-      out['gpu_over_cpu'] = out['whole_state_gate_applies_per_s'] / out['cpu_baseline']['value']
+      out['cpu_baseline']['gpu_over_this_baseline'] = out['whole_state_gate_applies_per_s'] / out['cpu_baseline']['value']
     print(json.dumps(out))
 
 

@@ -54,6 +54,68 @@ import numpy as np
 NO_CTL = -(2 ** 31)
 
 
+# ---- what a rank needs, and what a step should cost (the first real multi-GPU line is judged against these) ----
+XGMI_LINK_GBPS = 153.0          # per link and direction, peak (AMD's public figure; 7 links per GPU, one per peer in an 8-GPU node)
+SWEEP_MS_AT_2P33 = 46.7         # one relayout sweep over a 2^33-amplitude complex128 shard, measured (profiles/r05/qft33_kernel_stats.csv)
+PACK_GBPS = 5000.0              # gather / scatter kernels of packed rounds: bytes moved per second (k_xpack / k_xunpack stream like a sweep)
+
+
+def memory_plan(nbits, world, bit_width=128, chunk_amps=1 << 22):
+  """Device memory ONE rank asks for, in bytes: the shard, the second buffer relayout sweeps need, the staging halves of
+  the exchange (two send + two receive halves of (P-1) chunks: exchange.hip.h).  `need_in_place` is the floor (a rank that
+  cannot get the second buffer makes every rank fall back to in-place sweeps), `need_relayout` the default."""
+  g = int(math.log2(world))
+  nloc = int(nbits) - g
+  amp = 16 if int(bit_width) == 128 else 8
+  shard = amp << nloc
+  chunk = min(int(chunk_amps), 1 << max(0, nloc - 1))
+  staging = 4 * (world - 1) * chunk * amp if world > 1 else 0
+  return {'qubits': int(nbits), 'ranks': int(world), 'local_qubits': nloc, 'shard_bytes': shard, 'second_buffer_bytes': shard,
+          'staging_bytes': staging, 'need_in_place_bytes': shard + staging, 'need_relayout_bytes': 2 * shard + staging}
+
+
+def predict_step_ms(nbits, world, *, sweeps=None, exchanges=None, bit_width=128, link_efficiency=0.7, overlap_efficiency=0.8):
+  """Predicted time of ONE n-qubit QFT on `world` GPUs, so that a measured line can be called good or bad:
+    sweeps x t_sweep            t_sweep = 46.7 ms x 2^(local qubits - 33) (measured at 2^33; complex64: half), 3 sweeps on one GPU,
+                                4 with an exchange (tools/plan_sharded.py: what the planner does for every rung of the ladder)
+  + per exchange  max(t_link, t_pack + hidden) - hidden
+                                t_link  = shard / P bytes per link and direction (all-to-all: every peer's link carries 1/P of the
+                                          shard) / (153 GB/s x link_efficiency);
+                                t_pack  = the gather + scatter kernels of packed rounds: 4 x (P-1)/P x shard bytes at 5 TB/s,
+                                          on the same HBM the overlapped sweeps use;
+                                hidden  = overlap_efficiency x 2 x 7/8 x t_sweep: the slabs of the sweep before and of the sweep
+                                          after the exchange that run while the links are busy (8 slabs).
+  `expected` uses link_efficiency 0.7 / overlap 0.8, `best_case` 1.0 / 1.0.  Returns ms and the terms."""
+  g = int(math.log2(world))
+  nloc = int(nbits) - g
+  amp = 16 if int(bit_width) == 128 else 8
+  shard = amp << nloc
+  if sweeps is None:
+    sweeps = 3 if world == 1 else 4
+  if exchanges is None:
+    exchanges = 0 if world == 1 else 1
+  t_sweep = SWEEP_MS_AT_2P33 * 2.0 ** (nloc - 33) * (amp / 16.0)
+
+  def total(link_eff, ov):
+    if not exchanges:
+      return sweeps * t_sweep, 0.0, 0.0, 0.0
+    t_link = shard / world / (XGMI_LINK_GBPS * link_eff * 1e9) * 1e3
+    t_pack = 4.0 * (world - 1) / world * shard / (PACK_GBPS * 1e9) * 1e3
+    hidden = ov * 2 * 7 / 8 * t_sweep
+    window = max(t_link, t_pack + hidden)
+    return sweeps * t_sweep + exchanges * (window - hidden), t_link, t_pack, hidden
+  exp, t_link, t_pack, hidden = total(link_efficiency, overlap_efficiency)
+  best = total(1.0, 1.0)[0]
+  return {'expected_ms': exp, 'best_case_ms': best, 'sweeps': sweeps, 'exchanges': exchanges, 'sweep_ms': t_sweep,
+          'link_ms': t_link, 'pack_ms': t_pack, 'hidden_ms': hidden,
+          'assumptions': (f'{XGMI_LINK_GBPS:g} GB/s per xGMI link and direction x {link_efficiency:g}; sweep {SWEEP_MS_AT_2P33:g} ms per 2^33 '
+                          f'amplitudes (measured); packed rounds at {PACK_GBPS / 1e3:g} TB/s; {overlap_efficiency:g} of 2 x 7/8 sweeps hidden')}
+
+
+class MemoryPlanError(RuntimeError):
+  """A rank's shard + staging does not fit its free device memory (raised on EVERY rank, before anything is allocated)."""
+
+
 class ShardRouter:
   """The routing of a gate stream over the shard bits, as ONE rank does it: logical -> physical bit map, which
   gates force an exchange, which local bits give way (Belady), the bookkeeping of the swaps.  Pure Python over an
@@ -316,6 +378,7 @@ class ShardedState(ShardRouter):
     self.cdtype = np.complex128 if self.bit_width == 128 else np.complex64
     self._local_rank = local_rank
     nloc = int(nbits) - g
+    self.memory_plan = self._check_memory_plan(int(nbits), world, rank, local_rank, chunk_amps, engine_factory is None)
     factory = engine_factory or (lambda nl: _hip_engine_factory(nl, local_rank, fusion, self.bit_width))
     eng = factory(nloc)
     eng.set_shard(int(nbits), rank)     # the engine resolves shard-bit controls itself and sees every gate on every rank
@@ -326,6 +389,43 @@ class ShardedState(ShardRouter):
     if self.world > 1 or os.environ.get('QCC_EXCHANGE') == 'native':
       self._init_transport()
     self.relayout = self._agree_on_relayout()
+
+  def _check_memory_plan(self, nbits, world, rank, local_rank, chunk_amps, real_device):
+    """Before anything is allocated: what this rank will ask for (shard, second buffer, staging) against what the device
+    has free (hipMemGetInfo), printed per rank on stderr; if the floor -- shard + staging, in-place sweeps -- does not fit
+    on ANY rank, every rank raises MemoryPlanError (bench.py: one JSON line with "error") instead of an OOM mid-run."""
+    import sys
+    plan = memory_plan(nbits, world, self.bit_width, chunk_amps)
+    free = total = None
+    if real_device and self.torch.cuda.is_available():
+      try:
+        free, total = (int(v) for v in self.torch.cuda.mem_get_info(local_rank))
+      except Exception:  # pylint: disable=broad-except
+        free = total = None
+    margin = 512 << 20                       # op buffers, tables, the runtime's own
+    plan.update(free_bytes=free, total_bytes=total,
+                fits_in_place=None if free is None else bool(plan['need_in_place_bytes'] + margin <= free),
+                fits_relayout=None if free is None else bool(plan['need_relayout_bytes'] + margin <= free))
+    gib = lambda v: 'n/a' if v is None else f'{v / 2**30:.2f} GiB'   # noqa: E731
+    print(f'[qcc_amd.sharded rank {rank}/{world}] memory plan: shard {gib(plan["shard_bytes"])} + second buffer '
+          f'{gib(plan["second_buffer_bytes"])} + staging {gib(plan["staging_bytes"])} = {gib(plan["need_relayout_bytes"])} '
+          f'(in place: {gib(plan["need_in_place_bytes"])}); free {gib(free)} of {gib(total)}'
+          + ('' if plan['fits_relayout'] in (None, True) else
+             ('; no room for the second buffer: in-place sweeps on every rank' if plan['fits_in_place'] else '; DOES NOT FIT')),
+          file=sys.stderr, flush=True)
+    ok = 0 if plan['fits_in_place'] is False else 1
+    if world > 1:
+      t = self.torch.tensor([ok], dtype=self.torch.int32, device='cpu' if self.dist.get_backend() == 'gloo' else f'cuda:{local_rank}')
+      self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+      everyone = int(t.item())
+    else:
+      everyone = ok
+    if not everyone:
+      raise MemoryPlanError(
+          f'rank {rank}: ' + (f'shard + staging = {gib(plan["need_in_place_bytes"])} exceed the {gib(free)} free on device {local_rank}'
+                              if not ok else 'fits here, another rank does not have the room')
+          + f' ({nbits} qubits on {world} ranks = 2^{plan["local_qubits"]} amplitudes per rank)')
+    return plan
 
   def _init_transport(self):
     """The engine's exchange transport: RCCL under the nccl backend, host-staged rounds carried by gloo otherwise.

@@ -39,6 +39,9 @@ def test_bench_line_small():
   # value = gates x steps x (2^n / 2^30) / wall
   assert abs(d['value'] - 300 * 3 * 2 ** (24 - 30) / (d['ms_per_step'] * 3e-3)) / d['value'] < 1e-6
   assert 'cached_plan' in d and d['cached_plan']['ms_per_step'] > 0
+  # no GPU-over-CPU ratio at the top level of the line; the profile's traffic figure is named as such
+  assert 'gpu_over_cpu' not in d and c['gpu_over_this_baseline'] > 1
+  assert 'traffic_from_profile' in r and set(r['traffic_from_profile']) == {'bytes', 'source'}
 
 
 def test_bench_sharded_world_of_one():
@@ -71,3 +74,10 @@ def test_bench_multi_rank_launch_on_one_gpu(ranks):
   # what the communicator says about itself, and that the ranks compared their exchange geometry before data moved
   assert d['parity_max_abs'] is not None and d['parity_max_abs'] < 1e-10 and d['parity_samples_per_rank'] == 64
   assert d['rccl_ranks'] == ranks and d['exchange_verified'] is True and d['exchange_geometry_checks'] >= 1
+  # the prediction the measurement is judged against, and the per-rank memory plan checked before allocating
+  pr = d['predicted_ms_per_step']
+  assert pr['expected_ms'] >= pr['best_case_ms'] > 0 and pr['exchanges'] == d['exchanges_per_step'] and pr['sweeps'] >= 1
+  mp = d['memory_plan']
+  assert mp['ranks'] == ranks and mp['shard_bytes'] == 16 << (24 - ranks.bit_length() + 1) and mp['fits_in_place'] is True
+  assert mp['staging_bytes'] > 0 and mp['free_bytes'] > mp['need_relayout_bytes']
+  assert 'memory plan: shard' in r.stderr

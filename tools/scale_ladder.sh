@@ -35,3 +35,5 @@ for n in 1 2 4 8; do
   run "weak_q$((33 + g))_n$n" "$n" $((33 + g))
   run "strong_q33_n$n" "$n" 33
 done
+# one summary: measured vs predicted, weak / strong efficiency, parity_max_abs, rccl_ranks, exchange_verified
+python tools/scale_summary.py "$out" > "$out/summary.json" && echo "summary: $out/summary.json"
