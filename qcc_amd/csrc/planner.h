@@ -1915,18 +1915,94 @@ inline bool plan_has_far_tile(const PlanResult &pr) {
   return false;
 }
 
+// ---- what a planned sweep costs (round 6: the objective of plan_best) --------------------------------------------------------
+// The op streams of these sweeps run against the socket's 1 400 W: time is ENERGY.  Socket energy of one
+// tile's op stream in nJ, every op and DIAG group priced by the wave-instructions tools/gen_sweep_asm.py emits for it
+// (complex128 counts; the same classes and figures as tools/plan_valu_cost.py, which SQ_INSTS_VALU confirms to 2 %) times the
+// measured price per instruction kind (profiles/r04/valu_power_per_instruction.txt: v_fma_f64 2.0, v_mul_f64 1.9, v_add_f64
+// 1.5, DPP move 0.75, v_permlane swap 1.2, v_xor_b32 1.0 nJ).
+inline double sweep_op_energy_nj(const SweepPlan &sp) {
+  const double nr = (double)(1u << sp.rb);
+  double e = 0;
+  for (const SweepOp &op : sp.ops) {
+    const uint32_t f = op.flags;
+    if (f & OPF_GHOST) continue;
+    switch (op.kind) {
+      case OP_DENSE_REG:
+        if ((f & OPF_BFLY) && (f & (OPF_ROT_P | OPF_ROT_M))) e += 3 * nr * 1.58;
+        else if (f & OPF_BFLY) e += 2 * nr * 1.5;
+        else if (f & OPF_REAL) e += 5 * nr * 1.9;
+        else e += (10 * nr + 10) * 1.95;
+        break;
+      case OP_DENSE_LANE:
+        if ((f & OPF_LANE_DPP) && (f & OPF_BFLY)) e += (nr * (op.tb == 2 ? 10 : 6) + 14) * 1.0;
+        else if (f & OPF_LANE_DPP) e += (nr * (op.tb == 2 ? 12 : 8) + 20) * 1.1;
+        else if (f & OPF_BFLY) e += (2 * nr + 8) * 1.5 + 4 * nr * 1.0;         // + the LDS shuffles (ds_bpermute: ~1 nJ each, by time)
+        else e += (((f & OPF_REAL) ? 4 : 10) * nr + 30) * 1.9 + 4 * nr * 1.0;
+        break;
+      case OP_LSWAP: e += (2 * nr + 8) * 1.2; break;
+      case OP_WSWAP: e += 5 * 1.0 + 2 * nr * 1.0; break;                       // 16 + 16 ds_*_b128 per wave and the barrier's wait
+      case OP_DIAG: {
+        bool c_touched = false, c_sign = false;
+        for (uint32_t gi = 0; gi < op.n_groups; ++gi) {
+          const DGroup &g = sp.groups[op.group_off + gi];
+          const double slots = nr / (double)(1u << popc((uint64_t)g.reg_mask));
+          const bool general = (g.flags & DG_LTAB) || g.ntab || g.n_oterms;
+          const bool sign = g.re == -1.0 && g.im == 0.0 && !(g.flags & DG_LTAB) && !g.ntab;
+          if (g.flags & DG_BITFAC) { e += (124 + ((g.lane_mask || general) ? 11 : 0)) * 1.95; continue; }
+          if (sign) {
+            if (!g.reg_mask) { e += 6 * 1.0; c_touched = c_sign = true; }
+            else e += (4 + 2 * slots) * 1.0;
+            continue;
+          }
+          double pro = 0;
+          if (general) pro = 4 + 4 * g.ntab + 4 * g.n_oterms + ((g.flags & DG_LTAB) ? 4 : 7);
+          else if (g.lane_mask) pro = 11;
+          if (!g.reg_mask) { e += (pro + 4) * 1.9; c_touched = true; c_sign = false; }
+          else e += 4 * slots * 1.95 + pro * 1.0;
+        }
+        if (c_touched && !(f & OPF_DEFER_C)) e += (c_sign ? (2 * nr + 1) : 4 * nr) * 1.95;
+        break;
+      }
+      default: break;
+    }
+  }
+  return e;
+}
+
+// Predicted time of a plan in ms.  A sweep is a stream of 2 x (state bytes) through HBM beside its op stream, under the
+// socket's power limit: (fixed energy of the stream + op energy) / 1 400 W, never faster than the stream alone.  The two
+// constants are the round-5 measurements of a 2^30-amplitude complex128 state (profiles/r05): three QFT sweeps of 2.1 J of
+// ops each take 5.74 ms, four supremacy sweeps of 3.9 J each 7.0-7.2 ms  =>  ~6.0 J fixed per sweep; an op-light sweep
+// streams in 5.4 ms.  Both scale with the bytes swept (fixed bits fold the tile count; complex64 moves half).
+inline double plan_predicted_ms(const PlanResult &pr, int nloc, int bw) {
+  double ms = 0;
+  for (const SweepPlan &sp : pr.sweeps) {
+    const double scale = (double)sp.swept_bytes / (2.0 * 16.0 * (double)(1ull << 30));
+    const double e_ops_j = sweep_op_energy_nj(sp) * (double)sp.ntiles * 1e-9;
+    const double floor_ms = 5.4 * scale, fixed_j = 6.0 * scale;
+    ms += std::max(floor_ms, (fixed_j + e_ops_j) / 1400.0 * 1e3);
+  }
+  (void)nloc; (void)bw;
+  return ms;
+}
+
 inline PlanResult plan_best(const std::vector<GateRec> &queue, int nloc, uint64_t shard, int bw, int max_rb,
                             bool split_lanes, bool allow_relayout = false, bool keep_ghosts = false) {
   if (getenv("QH_WAVE_BITS")) return Planner(nloc, shard, bw, max_rb, split_lanes, -1, allow_relayout, keep_ghosts).plan(queue);
-  // the same choice from the tile selections alone (Planner::skeleton), then ONE full plan: a third of the
+  // the number of wave bits from the tile selections alone (Planner::skeleton), then ONE full plan: a third of the
   // planning time of three full plans (30-qubit QFT: 1.9 -> 0.9 ms)
   int best_wb = 1;
-  size_t best_n = 0;
-  bool have = false, best_far = false;
+  size_t best_n = 0, n_of[kMaxWaveBits + 1] = {0, 0, 0};
+  bool have = false, best_far = false, far_of[kMaxWaveBits + 1] = {false, false, false};
+  const int only_wb = env_int("QH_PLAN_ONLY_WB", -1);      // (probe: everything below with a pinned number of wave bits)
   for (int wb : {1, 2, 0}) {
+    if (only_wb >= 0 && wb != only_wb) continue;
     size_t n = 0;
     bool far = false;
     Planner(nloc, shard, bw, max_rb, split_lanes, wb, allow_relayout, keep_ghosts).skeleton(queue, &n, &far);
+    n_of[wb] = n;
+    far_of[wb] = far;
     if (!have || (best_far && !far) || (best_far == far && n < best_n)) {
       best_wb = wb;
       best_n = n;
@@ -1936,35 +2012,70 @@ inline PlanResult plan_best(const std::vector<GateRec> &queue, int nloc, uint64_
     if (best_n <= 1 && !best_far) break;
   }
   Planner chosen(nloc, shard, bw, max_rb, split_lanes, best_wb, allow_relayout, keep_ghosts);
-  // one sweep less?  Worth a search only where a sweep costs about what the search does: budget = the gate visits
+  // Fewer sweeps?  Worth a search only where a sweep costs about what the search does: budget = the gate visits
   // that fit into ~1.6 sweep times (2 x state bytes at 5.5 TB/s, ~2.5 ns per gate visit: 4 M visits = ~10 ms of host
   // time for a 16-GiB state, hidden behind the GPU whenever circuits are submitted back to back, paid once per
-  // circuit with the plan cache on; eight supremacy-30 instances: 5 6 6 6 7 7 6 6 sweeps greedy, 4 6 5 5 6 6 5 5 with
-  // the search).  QH_PLAN_SEARCH=0 switches it off, QH_PLAN_SEARCH_STEPS pins the budget.
+  // circuit with the plan cache on).  QH_PLAN_SEARCH=0 switches it off, QH_PLAN_SEARCH_STEPS pins the budget.
+  // Round 6: (1) a search that succeeds is repeated from the tiles it found (greedy 6 -> 5 -> 4 happens); (2) the search also
+  // runs with TWO wave bits (a tile of 13 bits instead of 12) when that can still save a sweep -- eight supremacy-30 instances:
+  // greedy 5 6 6 6 7 7 6 6 sweeps, round 5's search 4 5 5 5 6 6 5 5, now 4 4 5 5 5 6 5 5 --; (3) the candidates are compared
+  // by PREDICTED TIME (plan_predicted_ms: stream energy + op energy under the socket's power limit), not by sweep count alone.
   uint64_t dense_bits = 0;
   for (const GateRec &q : queue) if (q.tgt >= 0 && q.tgt < nloc && !plan_diag(q.g, q.tgt)) dense_bits |= 1ull << q.tgt;
   const int lane_low = bw == 128 ? 3 : 4;
-  const int cap = (kLaneBits - lane_low) + std::min({max_rb, max_reg_bits(bw), nloc - kLaneBits}) + best_wb;
-  const bool room = best_n >= 3 && popc(dense_bits >> lane_low) <= (int)(best_n - 1) * cap;   // every qubit visited at least once
-  if (room && env_flag("QH_PLAN_SEARCH", true)) {
+  const int cap0 = (kLaneBits - lane_low) + std::min({max_rb, max_reg_bits(bw), nloc - kLaneBits});
+  std::vector<PlanResult> cands;
+  if (best_n >= 3 && env_flag("QH_PLAN_SEARCH", true)) {
     const double sweep_us = 2.0 * (double)(bw == 128 ? 16 : 8) * (double)(1ull << nloc) / 5.5e6;
     uint64_t budget = std::min<uint64_t>((uint64_t)(sweep_us * 650.0), 8000000);      // ~1.6 sweep times of host work, at most ~20 ms
     if (const char *e = getenv("QH_PLAN_SEARCH_STEPS")) budget = strtoull(e, nullptr, 10);
-    if (budget >= 20000) {
-      std::vector<uint64_t> greedy;
+    const bool again = env_flag("QH_PLAN_SEARCH_AGAIN", true);
+    size_t target = best_n;           // sweeps of the best plan known so far
+    for (int wb : {best_wb, 2}) {
+      if (budget < 20000) break;
+      if (wb != best_wb && (best_wb != 1 || !env_flag("QH_PLAN_SEARCH_WB2", true) || far_of[2] || (only_wb >= 0 && only_wb != 2) ||
+                            target < 4 || n_of[2] == 0)) continue;
+      const int cap = cap0 + wb;
+      std::vector<uint64_t> start;
       size_t n = 0;
       bool far = false;
-      Planner(nloc, shard, bw, max_rb, split_lanes, best_wb, allow_relayout, keep_ghosts).skeleton(queue, &n, &far, &greedy);
+      Planner(nloc, shard, bw, max_rb, split_lanes, wb, allow_relayout, keep_ghosts).skeleton(queue, &n, &far, &start);
       std::vector<std::vector<int>> tiles;
-      if (Planner(nloc, shard, bw, max_rb, split_lanes, best_wb, allow_relayout, keep_ghosts).search_tiles(queue, greedy, budget, &tiles)) {
-        Planner forced(nloc, shard, bw, max_rb, split_lanes, best_wb, allow_relayout, keep_ghosts);
-        forced.set_tiles(tiles);
-        PlanResult pr = forced.plan(queue);
-        if (pr.sweeps.size() < best_n && !plan_has_far_tile(pr)) return pr;     // (the model ignores relabelling: check)
+      bool found = false;
+      // every qubit must be visited at least once: K tiles of `cap` bits
+      while (start.size() >= 3 && popc(dense_bits >> lane_low) <= (int)(start.size() - 1) * cap) {
+        std::vector<std::vector<int>> fewer;
+        if (!Planner(nloc, shard, bw, max_rb, split_lanes, wb, allow_relayout, keep_ghosts).search_tiles(queue, start, budget, &fewer)) break;
+        tiles.swap(fewer);
+        found = true;
+        if (!again) break;
+        start.clear();
+        for (const auto &t : tiles) {
+          uint64_t m = 0;
+          for (int b : t) m |= 1ull << b;
+          start.push_back(m);
+        }
+      }
+      if (!found || tiles.size() >= target) continue;
+      Planner forced(nloc, shard, bw, max_rb, split_lanes, wb, allow_relayout, keep_ghosts);
+      forced.set_tiles(tiles);
+      PlanResult pr = forced.plan(queue);
+      if (pr.sweeps.size() < target && !plan_has_far_tile(pr)) {     // (the model ignores relabelling: check)
+        target = pr.sweeps.size();
+        cands.push_back(std::move(pr));
       }
     }
   }
-  return chosen.plan(queue);
+  if (cands.empty()) return chosen.plan(queue);
+  if (cands.size() == 1 && !env_flag("QH_PLAN_COMPARE_GREEDY", false)) return std::move(cands[0]);
+  cands.push_back(chosen.plan(queue));
+  size_t best = 0;
+  double best_ms = 0;
+  for (size_t i = 0; i < cands.size(); ++i) {
+    const double ms = plan_predicted_ms(cands[i], nloc, bw);
+    if (i == 0 || ms < best_ms) { best = i; best_ms = ms; }
+  }
+  return std::move(cands[best]);
 }
 
 inline std::string plan_to_json(const std::vector<GateRec> &queue, int nloc, uint64_t shard, int bw = 128,

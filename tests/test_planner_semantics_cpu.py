@@ -245,7 +245,13 @@ def test_tile_search_saves_a_sweep_and_keeps_the_amplitudes(oracle, monkeypatch)
   # the budget is spent on independent attempts (walks are heavy-tailed): seed 1 gets 6 -> 5, which one long walk misses
   ops1, g81 = workloads.supremacy_stream(30, 20, seed=1).arrays()
   monkeypatch.setenv('QH_PLAN_SEARCH_STEPS', '4000000')      # (pinned: the default scales with the sweep time)
+  monkeypatch.setenv('QH_PLAN_SEARCH_WB2', '0')
   assert len(_plan(30, ops1, g81)['sweeps']) == 5
+  # round 6: the search also runs with two wave bits (13-bit tiles) when that can still save a sweep: seed 1 6 -> 5 -> 4
+  monkeypatch.delenv('QH_PLAN_SEARCH_WB2')
+  p1 = _plan(30, ops1, g81)
+  assert len(p1['sweeps']) == 4 and any(len(s['wavepos']) == 2 for s in p1['sweeps'])
+  assert sum(s['gates'] for s in p1['sweeps']) + p1['noop_gates'] == len(ops1)
   again = _plan(30, ops, g8)                                 # deterministic: same circuit, same tiles
   assert [s['regpos'] for s in again['sweeps']] == [s['regpos'] for s in _plan(30, ops, g8)['sweeps']]
   monkeypatch.setenv('QH_PLAN_SEARCH_STEPS', '4000000')      # (small states get no budget by default: a sweep is cheap there)
