@@ -51,6 +51,12 @@ def test_loopback_exchange_equals_x_gate(oracle, monkeypatch, transport, pack, n
   rounds are then packed by a gather kernel; 'packed' / 'direct' force either way of moving a round."""
   if pack != 'auto':
     monkeypatch.setenv('QH_EXCHANGE_PACK', '1' if pack == 'packed' else '0')
+  if pack == 'direct' and (n, bit) in ((22, 21), (24, 9)):
+    # Direct rounds are what the engine chooses when the blocks' bits give long runs: forced on a re-laid-out state they
+    # degenerate into 128-byte pieces (2^18 sends per exchange: 166 + 113 s of the round-5 suite for these two cases).  Here
+    # they run on the layout they are made for (no relayout sweeps); the scrambled-layout form of the forced direct path stays
+    # covered by the (22, 13, 2^10) and the complex64 cases.
+    monkeypatch.setenv('QH_RELAYOUT', '0')
   a_ops, a_g = _circuit(n, 100 + bit, 40)
   b_ops, b_g = _circuit(n, 200 + bit, 40)
   q_ops, q_g = workloads.qft_stream(range(n)).arrays()

@@ -49,8 +49,10 @@ def test_config3_supremacy_30q_depth20():
   assert np.max(np.abs(a - b)) <= 1e-10
 
 
-def test_config3_supremacy_28q_against_the_oracle():
-  """Config 3's circuit family against the CPU ORACLE at a size the host finishes in seconds (VERDICT r2, next #6:
+@pytest.mark.parametrize('seed', [0, 1])
+def test_config3_supremacy_28q_against_the_oracle(seed):
+  """(seed 1: VERDICT r05 #4 -- SURVEY 8(d) names seeds 0, 1, 2; since round 6 these instances plan with two wave bits, 13-bit
+  tiles found by the repeated tile search, 4 sweeps.)  Config 3's circuit family against the CPU ORACLE at a size the host finishes in seconds (VERDICT r2, next #6:
   the 30-qubit run above is GPU-vs-GPU plus inverse; the largest oracle comparison of a random circuit was 20
   qubits).  supremacy.py:123-158,208-253 at 28 qubits, depth 20, random.seed(0): every gate through
   oracle/xgates_oracle.c's restatement of xgates.cc:23-67 on all host cores (2^28 amplitudes, 4 GiB), the fused
@@ -58,7 +60,7 @@ def test_config3_supremacy_28q_against_the_oracle():
   import time
   from tests import oracle_lib
   n = 28
-  ops, g8 = workloads.supremacy_stream(n, 20, seed=0).arrays()
+  ops, g8 = workloads.supremacy_stream(n, 20, seed=seed).arrays()
   assert len(ops) > 300
   omp = oracle_lib.load(omp=True)
   want = np.empty(1 << n, dtype=np.complex128)
@@ -77,7 +79,7 @@ def test_config3_supremacy_28q_against_the_oracle():
     assert abs(st.norm2() - 1.0) < 1e-10
     got = [st.download(o, width) for o in offs]
   worst = max(float(np.max(np.abs(g - want[o:o + width]))) for g, o in zip(got, offs))
-  print(f'supremacy-28 ({len(ops)} gates): oracle {t_cpu:.1f} s on the host cores, {sweeps} sweeps on the GPU, max |gpu - oracle| = {worst:.2e}')
+  print(f'supremacy-28 seed {seed} ({len(ops)} gates): oracle {t_cpu:.1f} s on the host cores, {sweeps} sweeps on the GPU, max |gpu - oracle| = {worst:.2e}')
   assert float(np.max(np.abs(want[:width]))) > 1e-7          # dense state
   assert worst <= 1e-10
 

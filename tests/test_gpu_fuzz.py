@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_fuzz_fused_vs_oracle(env):
   e = dict(os.environ)
   e.update(env)
-  r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'fuzz_parity.py'), '12', '4242'], env=e, cwd=ROOT,
+  r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'fuzz_parity.py'), '8', '4242'], env=e, cwd=ROOT,
                      capture_output=True, text=True, timeout=300)
   assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
   assert '"failures": 0' in r.stdout

@@ -3,7 +3,7 @@
 // matrix is a per-lane constant), beside the DPP lane butterflies it would replace.
 //   usage: mfmapower layout            lane maps of v_mfma_f64_4x4x4_4b_f64 found by one-hot probing, and the self-check of the
 //                                      fused group against a host 4x4 complex product
-//          mfmapower MODE SECONDS      MODE: mfma4 mfma16 fma add dppbf grp grpmix   (tools/probes/r06_mfmapower.py samples rocm-smi)
+//          mfmapower MODE SECONDS      MODE: mfma4 mfma16 fma add dppbf grp grpmix salu smem   (tools/probes/r06_mfmapower.py samples rocm-smi)
 // Occupancy as k_sweep: 256-thread blocks, 3 waves per SIMD.
 #include <hip/hip_runtime.h>
 #include <chrono>
@@ -227,6 +227,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   }
 }
 
+// scalar side of the island's interpreter: MODE 7 s_add_u32 / s_and_b32 / s_lshl_b32 chains, MODE 8 s_load_dwordx4 from 4 KiB (scalar cache hits)
+template <int MODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void ks(const uint32_t *tab, uint32_t *out, int iters) {
+  uint32_t a = blockIdx.x + 1, b = 0x9e3779b9u, c = 7;
+  for (int i = 0; i < iters; ++i) {
+    if (MODE == 7)
+      asm volatile(REP8("s_add_u32 %0, %0, %1\n\ts_and_b32 %2, %0, %1\n\ts_lshl_b32 %1, %1, 1\n\ts_xor_b32 %1, %1, %2\n\t"
+                        "s_add_u32 %0, %0, %2\n\ts_or_b32 %2, %2, 1\n\ts_sub_u32 %1, %1, %0\n\ts_and_b32 %0, %0, 0xffff\n\t")
+                   : "+s"(a), "+s"(b), "+s"(c) : : "scc");
+    if (MODE == 8) {
+      uint32_t off = (a * 16) & 0xff0;
+      typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+      u4 r;
+      asm volatile(REP8("s_load_dwordx4 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)\n\ts_add_u32 %2, %2, 16\n\ts_and_b32 %2, %2, 0xff0\n\t")
+                   : "=&s"(r), "+s"(tab), "+s"(off) : : "scc", "memory");
+      const uint32_t r0 = r.x, r3 = r.w;
+      a += r0 + r3;
+    }
+  }
+  if (a + b + c == 0x12345) out[0] = a;
+}
+
+template <int MODE> static void run_s(double secs, int per_iter, int iters, const char *unit) {
+  uint32_t *tab, *out; CK(hipMalloc(&tab, 8192)); CK(hipMalloc(&out, 64));
+  CK(hipMemset(tab, 1, 8192));
+  const int blocks = 256 * 3;
+  hipLaunchKernelGGL(ks<MODE>, dim3(blocks), dim3(256), 0, 0, tab, out, 10);
+  CK(hipDeviceSynchronize());
+  auto t0 = std::chrono::steady_clock::now();
+  long launches = 0;
+  double el = 0;
+  while (el < secs) {
+    for (int r = 0; r < 32; ++r) hipLaunchKernelGGL(ks<MODE>, dim3(blocks), dim3(256), 0, 0, tab, out, iters);
+    CK(hipDeviceSynchronize());
+    launches += 32;
+    el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  }
+  const double n = (double)launches * blocks * 4 * iters * per_iter;
+  printf("%s/s %.4g  (%.4f per SIMD-cycle at 2.4 GHz = one per %.1f cycles)  seconds %.2f\n", unit, n / el, n / el / (1024 * 2.4e9),
+         1024 * 2.4e9 * el / n, el);
+}
+
 template <int MODE> static void run(double secs, int per_iter, int iters, const char *unit) {
   double *out; CK(hipMalloc(&out, 64));
   const int blocks = 256 * 3;
@@ -257,6 +299,8 @@ int main(int argc, char **argv) {
   else if (!strcmp(m, "dppbf")) run<4>(secs, 1, 480, "lane-butterflies-of-32-slots");
   else if (!strcmp(m, "grp")) run<5>(secs, 1, 1000, "fused-groups-of-32-slots");
   else if (!strcmp(m, "grpmix")) run<6>(secs, 1, 1000, "fused-groups-of-32-slots(+256 v_add_f64)");
+  else if (!strcmp(m, "salu")) run_s<7>(secs, 64, 20000, "scalar-ALU wave-instructions");
+  else if (!strcmp(m, "smem")) run_s<8>(secs, 8, 4000, "s_load_dwordx4 (+ wait + 2 scalar ALU)");
   else printf("idle\n");
   return 0;
 }

@@ -5,6 +5,7 @@ kinds it would replace, at k_sweep's occupancy; the same sampling as round 4's V
 import json
 import os
 import subprocess
+import sys
 import time
 
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -19,10 +20,12 @@ def smi():
   return p, int(s.strip('()').replace('Mhz', ''))
 
 
-print(subprocess.run([EXE, 'layout'], capture_output=True, text=True).stdout)
+if len(sys.argv) == 1:
+  print(subprocess.run([EXE, 'layout'], capture_output=True, text=True).stdout)
 idle = smi()
 print(f'idle: {idle[0]:.0f} W, sclk {idle[1]} MHz')
-for mode in ('fma', 'add', 'mfma4', 'mfma16', 'dppbf', 'grp', 'grpmix'):
+MODES = sys.argv[1:] or ['fma', 'add', 'mfma4', 'mfma16', 'dppbf', 'grp', 'grpmix', 'salu', 'smem']
+for mode in MODES:
   p = subprocess.Popen([EXE, mode, '8'], stdout=subprocess.PIPE, text=True)
   time.sleep(2.5)
   samples = []
