@@ -384,7 +384,8 @@ class Planner {
     }
   }
   bool search_tiles(const std::vector<GateRec> &queue, const std::vector<uint64_t> &greedy_tiles, uint64_t step_budget,
-                    std::vector<std::vector<int>> *tiles_out) {
+                    std::vector<std::vector<int>> *tiles_out, uint64_t *steps_used = nullptr) {
+    if (steps_used) *steps_used = 0;
     const size_t K = greedy_tiles.size() - 1;
     if (K < 2) return false;
     std::vector<GateRec> pending;
@@ -501,6 +502,7 @@ class Planner {
       }
       fruitless = abest == start_left ? fruitless + 1 : 0;
     }
+    if (steps_used) *steps_used = steps;
     if (best > 0) return false;
     tiles_out->clear();
     for (uint64_t t : best_tiles) {
@@ -2031,8 +2033,14 @@ inline PlanResult plan_best(const std::vector<GateRec> &queue, int nloc, uint64_
     if (const char *e = getenv("QH_PLAN_SEARCH_STEPS")) budget = strtoull(e, nullptr, 10);
     const bool again = env_flag("QH_PLAN_SEARCH_AGAIN", true);
     size_t target = best_n;           // sweeps of the best plan known so far
-    for (int wb : {best_wb, 2}) {
-      if (budget < 20000) break;
+    // ALL searches of a flush draw from one pool of 1.5 budgets (~15 ms of host time for a 16-GiB state at most, usually a few:
+    // a search that succeeds stops early): planning must stay below the time the GPU needs for the previous flush, behind which
+    // it hides when circuits are submitted back to back (bench.py plans every step from scratch)
+    uint64_t pool = budget + budget / 2;
+    for (int pass = 0; pass < 2; ++pass) {
+      const int wb = pass == 0 ? best_wb : 2;
+      if (pass == 1 && best_wb == 2) break;          // (the first search was the two-wave-bit one)
+      if (budget < 20000 || pool < 20000) break;
       if (wb != best_wb && (best_wb != 1 || !env_flag("QH_PLAN_SEARCH_WB2", true) || far_of[2] || (only_wb >= 0 && only_wb != 2) ||
                             target < 4 || n_of[2] == 0)) continue;
       const int cap = cap0 + wb;
@@ -2045,10 +2053,14 @@ inline PlanResult plan_best(const std::vector<GateRec> &queue, int nloc, uint64_
       // every qubit must be visited at least once: K tiles of `cap` bits
       while (start.size() >= 3 && popc(dense_bits >> lane_low) <= (int)(start.size() - 1) * cap) {
         std::vector<std::vector<int>> fewer;
-        if (!Planner(nloc, shard, bw, max_rb, split_lanes, wb, allow_relayout, keep_ghosts).search_tiles(queue, start, budget, &fewer)) break;
+        uint64_t used = 0;
+        const bool ok = pool >= 20000 &&
+            Planner(nloc, shard, bw, max_rb, split_lanes, wb, allow_relayout, keep_ghosts).search_tiles(queue, start, std::min(budget, pool), &fewer, &used);
+        pool -= std::min(pool, used);
+        if (!ok) break;
         tiles.swap(fewer);
         found = true;
-        if (!again) break;
+        if (!again || (pass == 0 && wb != 2)) break;   // (repeated on the two-wave-bit chain only: with one wave bit a second search never found anything)
         start.clear();
         for (const auto &t : tiles) {
           uint64_t m = 0;
