@@ -1,16 +1,16 @@
 #!/bin/bash
-# The round's evidence set (GPU box) -> gpurun_out/r${ROUND:-05}p/ (copied to profiles/rNN/): the default bench line (every config, the
+# The round's evidence set (GPU box) -> gpurun_out/r${ROUND:-06}p/ (copied to profiles/rNN/): the default bench line (every config, the
 # unfused entry, single shot, CPU baseline), the driver-style line, kernel statistics over post-warm-up dispatches for the
 # fused QFT, supremacy-30, complex64, 33 qubits, Grover-34 and the PER-GATE kernels, FETCH / WRITE PMC passes (traffic)
 # for every config of the line, SQ counters of supremacy-30 and the QFT.  ONE session.
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/r${ROUND:-05}p
+O=$R/gpurun_out/r${ROUND:-06}p
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-ladder-base --no-cached-plan --no-configs"
+B="python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-ladder-base --no-cached-plan --no-configs --no-live-traffic"
 U="python $R/bench.py --fusion 0 --steps 3 --warmup 1 --no-cpu-baseline"
 timeout 1200 python $R/bench.py > $O/bench_default.json 2> $O/bench_default.err
-timeout 600 python $R/bench.py --steps 20 --warmup 5 --no-configs > $O/bench_driver_style.json 2> $O/bench_driver_style.err
+timeout 600 python $R/bench.py --steps 20 --warmup 5 --no-configs --no-live-traffic > $O/bench_driver_style.json 2> $O/bench_driver_style.err
 timeout 300 python $R/bench.py --fusion 0 --steps 2 --no-cpu-baseline > $O/bench_unfused.json 2> $O/bench_unfused.err
 trace() {  # trace <tag> <skip sweeps> <command...>: kernel trace -> steady-state stats
   local tag=$1 skip=$2; shift 2
@@ -41,6 +41,8 @@ PY
 }
 trace fused 6 $B                                    # 2 warm-up steps x 3 sweeps dropped
 trace sup30 8 python $R/tools/run_workload.py sup30 5      # first two circuits dropped
+trace sup30s1 8 python $R/tools/run_workload.py sup30s1 5  # (round 6: 4 sweeps with two wave bits)
+trace sup30s2 10 python $R/tools/run_workload.py sup30s2 5 # (5 sweeps)
 trace qft30c64 6 python $R/tools/run_workload.py qft30c64 5
 trace qft33 6 python $R/tools/run_workload.py qft33 4
 trace grover34 9 python $R/tools/run_workload.py grover34 2     # the first iteration (9 sweeps) dropped
