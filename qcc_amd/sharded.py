@@ -484,7 +484,10 @@ class ShardedState(ShardRouter):
       return False
     if self.world == 1:
       return None                            # the engine decides at its first flush, like any single-GPU handle
-    mine = 1 if self.eng.set_relayout(True) else 0
+    # (the memory plan first: a second buffer that fits only by taking the room of the exchange's staging halves would turn
+    #  into an allocation failure at the first exchange -- such a rank votes for in-place sweeps without trying)
+    fits = getattr(self, 'memory_plan', {}).get('fits_relayout')
+    mine = 1 if fits is not False and self.eng.set_relayout(True) else 0
     t = self.torch.tensor([mine], dtype=self.torch.int32, device=self._red_device())
     self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
     if int(t.item()) == 0:
