@@ -500,7 +500,15 @@ class Planner {
           ++walks_without_gain;               // (four walks from the best tiles without a better one: next attempt)
         }
       }
+      if (env_flag("QH_PLAN_SEARCH_LOG", false))
+        fprintf(stderr, "[qh plan search]   K=%zu attempt %llu: start left-over %zu, best of attempt %zu, best so far %zu, visits %llu\n", K,
+                (unsigned long long)attempt, start_left, abest, best, (unsigned long long)steps);
       fruitless = abest == start_left ? fruitless + 1 : 0;
+      // Round 6: a search that will succeed is close after its first attempts -- supremacy-30, twelve searches: the best left-over
+      // after attempt 0 was 0-6 gates for the eleven that emptied the queue later, 26-56 for every one that never did -- so two
+      // attempts that leave more than a dozen gates end it: a failing search costs a quarter of its budget instead of all of it
+      // (it is the LAST search of every chain that fails: ~10 ms of host time per new circuit otherwise).
+      if (attempt >= 1 && best > 12) break;
     }
     if (steps_used) *steps_used = steps;
     if (best > 0) return false;
@@ -2057,6 +2065,9 @@ inline PlanResult plan_best(const std::vector<GateRec> &queue, int nloc, uint64_
         const bool ok = pool >= 20000 &&
             Planner(nloc, shard, bw, max_rb, split_lanes, wb, allow_relayout, keep_ghosts).search_tiles(queue, start, std::min(budget, pool), &fewer, &used);
         pool -= std::min(pool, used);
+        if (env_flag("QH_PLAN_SEARCH_LOG", false))
+          fprintf(stderr, "[qh plan search] wave bits %d: %zu -> %zu tiles %s after %llu visits (budget %llu, pool left %llu)\n", wb, start.size(),
+                  start.size() - 1, ok ? "found" : "not found", (unsigned long long)used, (unsigned long long)budget, (unsigned long long)pool);
         if (!ok) break;
         tiles.swap(fewer);
         found = true;
