@@ -55,6 +55,7 @@ def parse():
   ap.add_argument('--fusion', type=int, default=-1, help='0 per-gate kernels, 1 fused sweeps (default)')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-cached-plan', action='store_true', help='skip the extra steps timed with the plan cache on')
+  ap.add_argument('--no-energy', action='store_true', help='N=1: skip the Joules-per-launch measurement (two 4-s loops under rocm-smi)')
   ap.add_argument('--no-live-traffic', action='store_true',
                   help='N=1: do not measure roofline.traffic with rocprofv3 in this run (the committed profile is quoted instead)')
   ap.add_argument('--sharded', action='store_true', help='use the multi-GPU layer even with one rank (smoke)')
@@ -154,6 +155,74 @@ def live_traffic(workload='qft30', reps=2, timeout_s=150):
     return None, f'{type(e).__name__}: {e}'
   finally:
     shutil.rmtree(tmp, ignore_errors=True)
+
+
+def energy_roofline(device_index, seconds=4.0):
+  """Joules per k_sweep launch -- the second roofline of these sweeps (the socket's 1 400 W limit).  Two loops of
+  `seconds` each on a 30-qubit state while rocm-smi is sampled (~3 Hz, median): (a) a sweep with an EMPTY op stream (one T gate: the
+  tile stream of k_sweep and nothing else) = the floor in time AND energy of this launch shape, (b) the headline's QFT.  J per launch
+  = socket W x ms per launch.  None where rocm-smi is not available."""
+  import shutil
+  import subprocess
+  import threading
+  from qcc_amd import device, gates, native, workloads
+  if shutil.which('rocm-smi') is None:
+    return None
+
+  def smi():
+    r = subprocess.run(['rocm-smi', '-d', str(device_index), '--showpower', '--showclocks', '--json'], capture_output=True, text=True, timeout=10)
+    card = next(iter(json.loads(r.stdout).values()))
+    return float(card['Current Socket Graphics Package Power (W)']), int(card.get('sclk clock speed:', '(0Mhz)').strip('()').replace('Mhz', ''))
+
+  try:
+    idle_w, _ = smi()
+    n = 30
+    t_ops = np.array([[workloads.NO_CTL, n - 1]], dtype=np.int32)
+    t_g = np.asarray(gates.tgate(), dtype=np.complex128).reshape(1, 4).view(np.float64).reshape(1, 8)
+    out = {'idle_W': idle_w, 'method': f'rocm-smi socket power, median over a {seconds:g}-s loop per workload; J = W x ms per k_sweep launch'}
+    for key, (ops, g8) in (('stream_only', (t_ops, t_g)), ('qft30', workloads.qft_stream(range(n)).arrays())):
+      with device.DeviceState(n, 128, device=device_index, fusion=native.QH_FUSE_SWEEP) as st:
+        st.init_basis(5)
+        for _ in range(6):
+          st.run_stream(ops, g8)
+          st.flush()
+        st.sync()
+        samples, stop = [], [False]
+
+        def sampler():
+          time.sleep(1.0)
+          while not stop[0]:
+            try:
+              samples.append(smi())
+            except Exception:  # pylint: disable=broad-except
+              pass
+            time.sleep(0.25)
+        th = threading.Thread(target=sampler)
+        th.start()
+        st.reset_stats()
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+          for _ in range(20):
+            st.run_stream(ops, g8)
+            st.flush()
+          st.sync()
+        dt = time.perf_counter() - t0
+        stop[0] = True
+        th.join()
+        launches = max(1, st.stats()['kernels_launched'])
+      if not samples:
+        return None
+      w = sorted(x[0] for x in samples)[len(samples) // 2]
+      ck = sorted(x[1] for x in samples)[len(samples) // 2]
+      ms = dt / launches * 1e3
+      out[key] = {'ms_per_launch': ms, 'socket_W': w, 'sclk_MHz': ck, 'J_per_launch': w * ms * 1e-3, 'samples': len(samples)}
+    out['frac_of_floor_energy'] = out['stream_only']['J_per_launch'] / out['qft30']['J_per_launch']
+    out['frac_of_floor_time'] = out['stream_only']['ms_per_launch'] / out['qft30']['ms_per_launch']
+    out['note'] = ('stream_only = k_sweep with an empty op stream (same launch shape, same bytes): what the memory system alone takes and draws; '
+                   'the distance of qft30 from it is the op stream (VALU 4.0 G + scalar 2.1 G instructions per QFT), paid in Joules under the 1 400 W limit')
+    return out
+  except Exception as e:  # pylint: disable=broad-except
+    return {'error': repr(e)}
 
 
 def cpu_baseline(args, ops, g8):
@@ -639,6 +708,8 @@ def main():
         out['roofline']['traffic'], out['roofline']['traffic_source'] = t_live, why
       else:
         out['roofline']['traffic_source'] = f"{out['roofline']['traffic_source']} (committed profile; live measurement unavailable: {why})"
+    if extras and not args.no_energy:
+      out['roofline']['energy'] = energy_roofline(local_rank)
     if extras and not args.no_configs:
       # before the 128- and 256-GiB states below: the allocation that follows the release of such a state pays ~6 s of driver
       # work deferred from the release (profiles/r05/alloc_second_buffer_ab.txt) -- rounds 4 and 5 reported it as this entry's

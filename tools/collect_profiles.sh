@@ -7,10 +7,10 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r${ROUND:-06}p
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-ladder-base --no-cached-plan --no-configs --no-live-traffic"
+B="python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-ladder-base --no-cached-plan --no-configs --no-live-traffic --no-energy"
 U="python $R/bench.py --fusion 0 --steps 3 --warmup 1 --no-cpu-baseline"
 timeout 1200 python $R/bench.py > $O/bench_default.json 2> $O/bench_default.err
-timeout 600 python $R/bench.py --steps 20 --warmup 5 --no-configs --no-live-traffic > $O/bench_driver_style.json 2> $O/bench_driver_style.err
+timeout 600 python $R/bench.py --steps 20 --warmup 5 --no-configs --no-live-traffic --no-energy > $O/bench_driver_style.json 2> $O/bench_driver_style.err
 timeout 300 python $R/bench.py --fusion 0 --steps 2 --no-cpu-baseline > $O/bench_unfused.json 2> $O/bench_unfused.err
 trace() {  # trace <tag> <skip sweeps> <command...>: kernel trace -> steady-state stats
   local tag=$1 skip=$2; shift 2
