@@ -44,6 +44,22 @@ def test_bench_line_small():
   assert 'traffic_from_profile' in r and set(r['traffic_from_profile']) == {'bytes', 'source'}
 
 
+def test_bench_headline_extras_at_full_size():
+  """The parts of the default line that only exist at the headline's size (30 qubits): `roofline.traffic` measured in the run
+  (rocprofv3 PMC passes in a child process -- or the committed profile's figure with the reason, where rocprofv3 cannot run) and
+  `roofline.energy` (Joules per k_sweep launch: stream-only floor vs the QFT).  Neither may cost the line."""
+  d = _run('--steps', '3', '--warmup', '1', '--no-configs', '--no-ladder-base', '--no-cpu-baseline', '--no-cached-plan')
+  r = d['roofline']
+  assert d['config']['qubits'] == 30 and r['bytes_per_launch'] == 2 * 16 * 2 ** 30 and 0.5 < r['frac'] < 1.0
+  assert r['traffic'] is not None and abs(r['traffic'] / r['bytes_per_launch'] - 1) < 0.01          # no wasted HBM traffic
+  assert 'measured in this run' in r['traffic_source'] or 'committed profile' in r['traffic_source']
+  assert r['traffic_from_profile']['bytes'] is not None
+  e = r['energy']
+  if e is not None and 'error' not in e:                        # (rocm-smi on the box)
+    assert 0.8 < e['frac_of_floor_time'] <= 1.05 and 0.3 < e['frac_of_floor_energy'] <= 1.05
+    assert e['stream_only']['J_per_launch'] > 1 and e['qft30']['socket_W'] > e['stream_only']['socket_W'] > e['idle_W'] * 0.5
+
+
 def test_bench_sharded_world_of_one():
   d = _run('--sharded', '--qubits', '22', '--steps', '2', '--warmup', '1', '--no-cpu-baseline', env={'QCC_EXCHANGE': 'native'})
   assert d['n_gpus'] == 1 and d['exchange_path'] == 'rccl' and d['exchanges_per_step'] == 0
