@@ -14,12 +14,14 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cassert>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/qcc_hip.h"
@@ -354,49 +356,31 @@ class Planner {
     }
   }
 
-  // ---- tile search ---------------------------------------------------------------------------------------
-  // The greedy selection maximises the gates of ONE sweep; layered circuits (supremacy: every qubit couples to
-  // its grid neighbours every few layers) can need a sweep less when an early sweep takes FEWER gates but leaves
-  // the frontier where the next one runs long (BASELINE config 3, seed 0: greedy 85+88+79+84+6 gates in 5 sweeps;
-  // 66+128+80+68 in 4 exists).  search_tiles() looks for K = greedy - 1 tiles that empty the queue: local search
-  // from the greedy tiles on the planner's own pass model -- replace a tile bit that ran few dense gates in its
-  // sweep by a bit whose gates were ready but not in the tile, accept if no more gates are left over than before,
-  // restart from the best tiles when stuck.  Deterministic (fixed seed, budget counted in gate visits, not in
-  // time: the ranks of a sharded state must find the same tiles).  Returns true and the tiles (bit numbering of
-  // the start of the flush) on success.
-  struct SearchSweep { std::vector<PassRec> rest; uint32_t cnt[64]; uint64_t want; };
-  void search_run(const std::vector<PassRec> &rec, uint64_t tilemask, SearchSweep *out, uint64_t *steps) const {
-    uint64_t blocked_all = 0, blocked_diag = 0;
-    out->rest.clear();
-    memset(out->cnt, 0, sizeof out->cnt);
-    out->want = 0;
-    *steps += rec.size();
-    for (const PassRec &r : rec) {
-      const bool can_pass = !(r.dense_bits & (blocked_all | blocked_diag)) && !(r.diag_bits & blocked_all);
-      if (can_pass && (!r.dense_bits || (tilemask & r.dense_bits))) {
-        if (r.dense_bits) out->cnt[r.tgt]++;
-      } else {
-        if (can_pass && r.dense_bits) out->want |= r.dense_bits;
-        blocked_all |= r.dense_bits;
-        blocked_diag |= r.diag_bits;
-        out->rest.push_back(r);
-      }
-    }
-  }
-  bool search_tiles(const std::vector<GateRec> &queue, const std::vector<uint64_t> &greedy_tiles, uint64_t step_budget,
-                    std::vector<std::vector<int>> *tiles_out, uint64_t *steps_used = nullptr) {
-    if (steps_used) *steps_used = 0;
-    const size_t K = greedy_tiles.size() - 1;
-    if (K < 2) return false;
-    std::vector<GateRec> pending;
-    std::vector<uint64_t> alg;
-    uint64_t noops = 0;
-    prepare(queue, &pending, &alg, &noops);
-    // The search runs on CANONICAL bit numbers -- index bits above the 128-byte line renumbered in the order the
-    // queue first uses them -- so that the same circuit gets the same walk, and the same answer, whatever layout
-    // earlier relayout sweeps have left the state in (a loop over one circuit sees a different layout every step).
+  // ---- level search ---------------------------------------------------------------------------------------
+  // The greedy selection maximises the gates of ONE sweep; layered circuits (supremacy: every qubit couples to its
+  // grid neighbours every few layers) can need a sweep less when an early sweep takes FEWER gates but leaves the
+  // frontier where the next one runs long (BASELINE config 3, seed 0: greedy 85+88+79+84+6 gates in 5 sweeps;
+  // 66+128+80+68 in 4 exists).  Rounds 3-6 looked for such tiles by local search over the TILES (the cap of a tile
+  // hard, "every gate runs" soft); round 6 replaced it by the search over the dual object.  A plan of K sweeps is a
+  // labelling L of the dense gates with levels 0..K-1 that never decreases along a dependency (K-1 nested cuts through
+  // the circuit; diagonal gates ride along: they need no tile bit and go to any sweep between their neighbours), and a
+  // sweep's tile is the set of qubits with a gate on its level: at most `cap` of them besides the line bits.  The
+  // search keeps the labelling VALID and the caps soft: a move lifts a gate and everything that must follow it one
+  // level up (or lowers it and what must precede it), the cost is the overflow sum(max(0, |tile_s| - cap)), ties by
+  // sum |tile_s|^2; tabu search over the evictions from overfull tiles (first gate of a qubit on the level up, last one
+  // down), short tenure, restarts from the depth-proportional labelling.  It finds 4-sweep tilings of supremacy-30
+  // seeds 2 3 4 6 7 in 2-20 ms where the tile search had found none in 2 x 10^9 gate visits (an integer program says
+  // they exist, and that seed 5 needs five: profiles/r06/level_search.txt).  Deterministic (generator seeded by
+  // `stream`, budget counted in label changes, canonical bit numbers): the ranks of a sharded state find the same tiles.
+  // `stop_at` (optional, shared between the streams of one (wave bits, K)): a stream gives up once it has spent more
+  // label changes than another stream needed to succeed -- the winner is the stream with the fewest, whatever the
+  // threads' timing was.  Returns true and the tiles (bit numbering of the start of the flush).
+  void canonical_records(const std::vector<GateRec> &pending, std::vector<PassRec> *rec0, int back[64], uint64_t *movable) {
+    // CANONICAL bit numbers -- index bits above the 128-byte line renumbered in the order the queue first uses them -- so
+    // that the same circuit gets the same walk, and the same answer, whatever layout earlier relayout sweeps have left
+    // the state in (a loop over one circuit sees a different layout every step).
     const uint64_t always = (1ull << lane_low_) - 1;
-    int canon[64], back[64], ncanon = lane_low_;
+    int canon[64], ncanon = lane_low_;
     for (int b = 0; b < 64; ++b) canon[b] = b < lane_low_ ? b : -1;
     auto canon_mask = [&](uint64_t m) {
       uint64_t o = 0;
@@ -407,115 +391,190 @@ class Planner {
       }
       return o;
     };
-    std::vector<PassRec> rec0(pending.size());
+    rec0->resize(pending.size());
     uint64_t dense_used = 0;
     for (size_t i = 0; i < pending.size(); ++i) {
       const GateRec &r = pending[i];
       const bool diag = plan_diag(r);
       const uint64_t tb = canon_mask((r.tgt >= 0) ? (1ull << r.tgt) : 0);
       const uint64_t cb = canon_mask((r.ctl_mask | r.neg_mask) & ((1ull << nloc_) - 1));
-      rec0[i] = PassRec{diag ? 0 : tb, cb | (diag ? tb : 0), 1, tb ? __builtin_ctzll(tb) : -1};
+      (*rec0)[i] = PassRec{diag ? 0 : tb, cb | (diag ? tb : 0), 1, tb ? __builtin_ctzll(tb) : -1};
       if (!diag) dense_used |= tb;
     }
+    for (int b = 0; b < 64; ++b) back[b] = -1;
     for (int b = 0; b < 64; ++b) if (canon[b] >= 0) back[canon[b]] = b;
-    const uint64_t movable = dense_used & ~always;
+    *movable = dense_used & ~always;
+  }
+  bool search_levels(const std::vector<GateRec> &queue, size_t K, uint64_t change_budget, uint64_t stream,
+                     std::vector<std::vector<int>> *tiles_out, uint64_t *changes_used = nullptr,
+                     std::atomic<uint64_t> *stop_at = nullptr) {
+    if (changes_used) *changes_used = 0;
+    if (K < 2 || K > 8) return false;
+    std::vector<GateRec> pending;
+    std::vector<uint64_t> alg;
+    uint64_t noops = 0;
+    prepare(queue, &pending, &alg, &noops);
+    std::vector<PassRec> rec0;
+    int back[64];
+    uint64_t movable = 0;
+    canonical_records(pending, &rec0, back, &movable);
+    const uint64_t always = (1ull << lane_low_) - 1;
     const int cap = lane_hi_ + rb_cap_ + max_wave_;
     if ((size_t)popc(movable) > K * (size_t)cap) return false;       // not even room to visit every qubit once
-    uint64_t rng = 0x9e3779b97f4a7c15ull;
-    auto rnd = [&](uint32_t n) { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return (uint32_t)((rng >> 11) % n); };
-    auto pick_bit = [&](uint64_t m) { int k = (int)rnd((uint32_t)popc(m)); while (k--) m &= m - 1; return __builtin_ctzll(m); };
-    std::vector<uint64_t> start, cur, best_tiles;
-    for (size_t k = 0; k < K; ++k) {
-      uint64_t t = 0;
-      for (uint64_t m = greedy_tiles[k] & ~always; m; m &= m - 1)
-        if (canon[__builtin_ctzll(m)] >= 0) t |= 1ull << canon[__builtin_ctzll(m)];
-      start.push_back(t & movable);
-    }
-    std::vector<SearchSweep> st(K), trial(K);
-    uint64_t steps = 0;
-    auto eval_from = [&](const std::vector<uint64_t> &tiles, size_t from, std::vector<SearchSweep> *out) {
-      for (size_t i = from; i < K; ++i) search_run(i ? (*out)[i - 1].rest : rec0, always | tiles[i], &(*out)[i], &steps);
-      return (*out)[K - 1].rest.size();
-    };
-    // The time a walk needs is heavy-tailed (supremacy-30, eight generators: 0.07-0.55 M gate visits when it
-    // succeeds, 3-5 M burnt when it has walked into a basin without a solution), so the budget is spent on
-    // ATTEMPTS: each starts from the greedy tiles with its own generator and gets an eighth of the budget (at least
-    // 0.3 M visits); the first that empties the queue wins.  Circuits without a solution mostly show it at once (the
-    // 34-qubit Grover iteration, one supremacy instance in twelve: no move ever lowers the left-over): two attempts in
-    // a row without any progress end the search.
-    constexpr int attempts = 8;
-    const uint64_t attempt_budget = std::max<uint64_t>(step_budget / attempts, 300000);
-    size_t best = ~(size_t)0;
-    const uint64_t rng0 = rng;
-    int fruitless = 0;       // attempts in a row that never got below the greedy tiles' left-over: two -> give up
-    for (uint64_t attempt = 0; best > 0 && steps < step_budget && fruitless < 2; ++attempt) {
-      rng = rng0 + attempt * 0xd1342543de82ef95ull;
-      if (!rng) rng = rng0;
-      const uint64_t attempt_end = std::min(step_budget, steps + attempt_budget);
-      cur = start;
-      size_t cv = eval_from(cur, 0, &st), abest = cv;
-      const size_t start_left = cv;
-      std::vector<uint64_t> abest_tiles = cur;
-      if (cv < best) { best = cv; best_tiles = cur; }
-      size_t since_improved = 0, walks_without_gain = 0;
-      while (best > 0 && steps < attempt_end && walks_without_gain < 4) {
-        const size_t i = rnd((uint32_t)K);
-        const uint64_t s = cur[i];
-        uint64_t wantb = st[i].want & ~s & movable;
-        if (!wantb || rnd(100) < 15) wantb = movable & ~s;
-        if (!wantb) continue;
-        uint64_t ns = s | (1ull << pick_bit(wantb));
-        if (popc(s) >= cap || rnd(100) >= 70) {
-          if (!s) continue;
-          uint32_t m = ~0u;
-          for (uint64_t t = s; t; t &= t - 1) m = std::min(m, st[i].cnt[__builtin_ctzll(t)]);
-          const uint32_t slack = rnd(100) < 30 ? 1 : 0;
-          uint64_t pool = 0;
-          for (uint64_t t = s; t; t &= t - 1) if (st[i].cnt[__builtin_ctzll(t)] <= m + slack) pool |= t & -t;
-          ns &= ~(1ull << pick_bit(pool));
+    // The dependency graph of the DENSE gates, as pass_fast / build_sweep order them: a dense gate follows the last dense
+    // gate on its target, the last dense gate on each of its control bits, and -- through every diagonal gate (or control)
+    // that touched its target since -- the last dense gates on the other bits of that gate; diagonal uses commute.
+    std::vector<int> node_bit;
+    std::vector<std::vector<int>> succ, pred;
+    {
+      int last_dense[64];
+      std::vector<int> need[64];
+      for (int b = 0; b < 64; ++b) last_dense[b] = -1;
+      for (const PassRec &r : rec0) {
+        if (!r.dense_bits) {
+          for (uint64_t t = r.diag_bits; t; t &= t - 1) {
+            const int b = __builtin_ctzll(t);
+            for (uint64_t u = r.diag_bits & ~(1ull << b); u; u &= u - 1)
+              if (last_dense[__builtin_ctzll(u)] >= 0) need[b].push_back(last_dense[__builtin_ctzll(u)]);
+          }
+          continue;
         }
-        if (ns == s || popc(ns) > cap) continue;       // (whether the positions suit a tile is checked when the plan is built)
-        for (size_t k = 0; k < i; ++k) trial[k].rest.clear();          // (prefix unchanged: evaluated from sweep i on)
-        std::vector<uint64_t> cand = cur;
-        cand[i] = ns;
-        // sweeps before i are those of `st`: run i.. on top of st[i-1]
-        {
-          const std::vector<PassRec> *src = i ? &st[i - 1].rest : &rec0;
-          search_run(*src, always | cand[i], &trial[i], &steps);
-          for (size_t k = i + 1; k < K; ++k) search_run(trial[k - 1].rest, always | cand[k], &trial[k], &steps);
-        }
-        const size_t v = trial[K - 1].rest.size();
-        if (v <= cv) {
-          for (size_t k = i; k < K; ++k) std::swap(st[k], trial[k]);
-          cur.swap(cand);
-          if (v < cv) since_improved = 0;
-          cv = v;
-          if (v < abest) { abest = v; abest_tiles = cur; walks_without_gain = 0; }
-          if (v < best) { best = v; best_tiles = cur; }
-        }
-        if (++since_improved > 1500) {        // stuck on a plateau: back to this attempt's best tiles, another walk
-          cur = abest_tiles;
-          cv = eval_from(cur, 0, &st);
-          since_improved = 0;
-          ++walks_without_gain;               // (four walks from the best tiles without a better one: next attempt)
-        }
+        const int v = (int)node_bit.size(), tb = r.tgt;
+        node_bit.push_back(tb);
+        succ.emplace_back();
+        pred.emplace_back();
+        std::vector<int> ps;
+        if (last_dense[tb] >= 0) ps.push_back(last_dense[tb]);
+        for (int u : need[tb]) ps.push_back(u);
+        for (uint64_t t = r.diag_bits; t; t &= t - 1) if (last_dense[__builtin_ctzll(t)] >= 0) ps.push_back(last_dense[__builtin_ctzll(t)]);
+        std::sort(ps.begin(), ps.end());
+        ps.erase(std::unique(ps.begin(), ps.end()), ps.end());
+        for (int u : ps) { succ[u].push_back(v); pred[v].push_back(u); }
+        need[tb].clear();
+        last_dense[tb] = v;
+        for (uint64_t t = r.diag_bits; t; t &= t - 1) need[__builtin_ctzll(t)].push_back(v);
       }
-      if (env_flag("QH_PLAN_SEARCH_LOG", false))
-        fprintf(stderr, "[qh plan search]   K=%zu attempt %llu: start left-over %zu, best of attempt %zu, best so far %zu, visits %llu\n", K,
-                (unsigned long long)attempt, start_left, abest, best, (unsigned long long)steps);
-      fruitless = abest == start_left ? fruitless + 1 : 0;
-      // Round 6: a search that will succeed is close after its first attempts -- supremacy-30, twelve searches: the best left-over
-      // after attempt 0 was 0-6 gates for the eleven that emptied the queue later, 26-56 for every one that never did -- so two
-      // attempts that leave more than a dozen gates end it: a failing search costs a quarter of its budget instead of all of it
-      // (it is the LAST search of every chain that fails: ~10 ms of host time per new circuit otherwise).
-      if (attempt >= 1 && best > 12) break;
     }
-    if (steps_used) *steps_used = steps;
-    if (best > 0) return false;
+    const int ng = (int)node_bit.size();
+    if (!ng) return false;
+    std::vector<int> depth(ng, 0);
+    int maxd = 0;
+    for (int u = 0; u < ng; ++u) for (int v : succ[u]) { depth[v] = std::max(depth[v], depth[u] + 1); maxd = std::max(maxd, depth[v]); }   // (nodes are in queue order: topological)
+    // per qubit: its nodes in order (the chain), for "first / last gate of q on level s"
+    std::vector<int> chain[64];
+    for (int g = 0; g < ng; ++g) chain[node_bit[g]].push_back(g);
+    std::vector<int8_t> L(ng);
+    int occ[64][8], ntile[8];       // gates of qubit q on level s; movable qubits on level s
+    uint64_t changes = 0;
+    auto set_level = [&](int g, int to) {
+      const int q = node_bit[g], from = L[g];
+      ++changes;
+      if (!((always >> q) & 1)) {
+        if (--occ[q][from] == 0) --ntile[from];
+        if (occ[q][to]++ == 0) ++ntile[to];
+      }
+      L[g] = (int8_t)to;
+    };
+    auto init = [&]() {
+      memset(occ, 0, sizeof occ);
+      memset(ntile, 0, sizeof ntile);
+      for (int g = 0; g < ng; ++g) {
+        L[g] = (int8_t)std::min<int>((int)K - 1, depth[g] * (int)K / (maxd + 1));
+        const int q = node_bit[g];
+        if (!((always >> q) & 1) && occ[q][L[g]]++ == 0) ++ntile[L[g]];
+      }
+    };
+    auto cost = [&](int *over) {
+      long sq = 0;
+      int o = 0;
+      for (size_t s = 0; s < K; ++s) { sq += (long)ntile[s] * ntile[s]; if (ntile[s] > cap) o += ntile[s] - cap; }
+      *over = o;
+      return (long)o * 100000 + sq;
+    };
+    std::vector<int> stk;
+    std::vector<std::pair<int, int8_t>> undo;
+    auto move = [&](int g, bool down) {       // lift g and what must follow it (lower g and what must precede it); false: out of range
+      const int to = L[g] + (down ? -1 : 1);
+      if (to < 0 || to >= (int)K) return false;
+      stk.assign(1, g);
+      undo.emplace_back(g, L[g]);
+      set_level(g, to);
+      while (!stk.empty()) {
+        const int u = stk.back();
+        stk.pop_back();
+        for (int v : down ? pred[u] : succ[u])
+          if (down ? L[v] > to : L[v] < to) { undo.emplace_back(v, L[v]); set_level(v, to); stk.push_back(v); }
+      }
+      return true;
+    };
+    auto revert = [&]() { for (size_t i = undo.size(); i-- > 0;) set_level(undo[i].first, undo[i].second); undo.clear(); };
+    uint64_t rng = 0x9e3779b97f4a7c15ull * (2 * stream + 1);
+    auto rnd = [&](uint32_t n) { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return (uint32_t)((rng >> 11) % n); };
+    constexpr long kRestart = 1500;       // iterations per walk (supremacy-30: a walk that succeeds mostly does within 1 000)
+    constexpr int kTenure = 7;            // a gate that moved stays put for 7-13 iterations (4-8 best of 2..50; 30: 20x slower)
+    std::vector<long> tabu((size_t)ng * 2);
+    std::vector<int> cands;
+    bool found = false;
+    int best_over_ever = 1 << 30;
+    for (long walk = 0; !found; ++walk) {
+      init();
+      std::fill(tabu.begin(), tabu.end(), -1);
+      int over = 0, best_over = 0;
+      long best_key = cost(&best_over);
+      over = best_over;
+      for (long it = 0; it < kRestart && over > 0; ++it) {
+        if (changes > change_budget || (stop_at && changes > stop_at->load(std::memory_order_relaxed))) goto out;
+        // a circuit without a K-sweep tiling shows it early (supremacy-30 with K = 3: the overflow never drops below 5; every
+        // instance that has one is at 1-4 after 400 iterations): the first walk ends the search then
+        if (walk == 0 && it == 400 && best_over > 4) goto out;
+        cands.clear();
+        for (size_t s = 0; s < K; ++s) {
+          if (ntile[s] <= cap) continue;
+          for (uint64_t t = movable; t; t &= t - 1) {
+            const int q = __builtin_ctzll(t);
+            if (!occ[q][s]) continue;
+            int first = -1, last = -1;
+            for (int g : chain[q]) if (L[g] == (int8_t)s) { if (first < 0) first = g; last = g; }
+            cands.push_back(first * 2);
+            cands.push_back(last * 2 + 1);
+          }
+        }
+        long bk = 1L << 60;
+        int bm = -1, ties = 0;
+        for (int m : cands) {
+          undo.clear();
+          if (!move(m >> 1, m & 1)) continue;
+          int o = 0;
+          const long k = cost(&o);
+          revert();
+          if (tabu[m] > it && !(o < best_over)) continue;
+          if (k < bk) { bk = k; bm = m; ties = 1; }
+          else if (k == bk && rnd((uint32_t)++ties) == 0) bm = m;
+        }
+        if (bm < 0) continue;
+        undo.clear();
+        move(bm >> 1, bm & 1);
+        const long k = cost(&over);
+        for (const auto &u : undo) tabu[(size_t)u.first * 2 + ((bm & 1) ? 0 : 1)] = it + kTenure + (long)rnd(kTenure);
+        if (k < best_key) { best_key = k; best_over = over; }
+      }
+      best_over_ever = std::min(best_over_ever, best_over);
+      found = over == 0;
+    }
+  out:
+    if (changes_used) *changes_used = changes;
+    if (env_flag("QH_PLAN_SEARCH_LOG", false))
+      fprintf(stderr, "[qh plan search]   K=%zu cap %d stream %llu: %s after %llu label changes\n", K, cap, (unsigned long long)stream,
+              found ? "found" : "not found", (unsigned long long)changes);
+    if (!found) return false;
+    if (stop_at) {      // (atomic minimum)
+      uint64_t cur = stop_at->load(std::memory_order_relaxed);
+      while (changes < cur && !stop_at->compare_exchange_weak(cur, changes, std::memory_order_relaxed)) {}
+    }
     tiles_out->clear();
-    for (uint64_t t : best_tiles) {
+    for (size_t s = 0; s < K; ++s) {
       std::vector<int> b;
-      for (; t; t &= t - 1) b.push_back(back[__builtin_ctzll(t)]);
+      for (uint64_t t = movable; t; t &= t - 1) if (occ[__builtin_ctzll(t)][s]) b.push_back(back[__builtin_ctzll(t)]);
       std::sort(b.begin(), b.end());
       tiles_out->push_back(b);
     }
@@ -2000,6 +2059,22 @@ inline double plan_predicted_ms(const PlanResult &pr, int nloc, int bw) {
 inline PlanResult plan_best(const std::vector<GateRec> &queue, int nloc, uint64_t shard, int bw, int max_rb,
                             bool split_lanes, bool allow_relayout = false, bool keep_ghosts = false) {
   if (getenv("QH_WAVE_BITS")) return Planner(nloc, shard, bw, max_rb, split_lanes, -1, allow_relayout, keep_ghosts).plan(queue);
+  if (const char *e = getenv("QH_PLAN_TILES")) {      // (probe: "wb:b,b,..;b,b,..": tiles in the bit numbering of the flush's start)
+    std::vector<std::vector<int>> tiles(1);
+    const int wb = atoi(e);
+    const char *p = strchr(e, ':');
+    for (p = p ? p + 1 : e; *p; ) {
+      if (*p == ';') { tiles.emplace_back(); ++p; continue; }
+      if (*p == ',') { ++p; continue; }
+      char *end = nullptr;
+      tiles.back().push_back((int)strtol(p, &end, 10));
+      if (end == p) break;
+      p = end;
+    }
+    Planner forced(nloc, shard, bw, max_rb, split_lanes, wb, allow_relayout, keep_ghosts);
+    forced.set_tiles(tiles);
+    return forced.plan(queue);
+  }
   // the number of wave bits from the tile selections alone (Planner::skeleton), then ONE full plan: a third of the
   // planning time of three full plans (30-qubit QFT: 1.9 -> 0.9 ms)
   int best_wb = 1;
@@ -2022,14 +2097,20 @@ inline PlanResult plan_best(const std::vector<GateRec> &queue, int nloc, uint64_
     if (best_n <= 1 && !best_far) break;
   }
   Planner chosen(nloc, shard, bw, max_rb, split_lanes, best_wb, allow_relayout, keep_ghosts);
-  // Fewer sweeps?  Worth a search only where a sweep costs about what the search does: budget = the gate visits
-  // that fit into ~1.6 sweep times (2 x state bytes at 5.5 TB/s, ~2.5 ns per gate visit: 4 M visits = ~10 ms of host
-  // time for a 16-GiB state, hidden behind the GPU whenever circuits are submitted back to back, paid once per
-  // circuit with the plan cache on).  QH_PLAN_SEARCH=0 switches it off, QH_PLAN_SEARCH_STEPS pins the budget.
-  // Round 6: (1) a search that succeeds is repeated from the tiles it found (greedy 6 -> 5 -> 4 happens); (2) the search also
-  // runs with TWO wave bits (a tile of 13 bits instead of 12) when that can still save a sweep -- eight supremacy-30 instances:
-  // greedy 5 6 6 6 7 7 6 6 sweeps, round 5's search 4 5 5 5 6 6 5 5, now 4 4 5 5 5 6 5 5 --; (3) the candidates are compared
-  // by PREDICTED TIME (plan_predicted_ms: stream energy + op energy under the socket's power limit), not by sweep count alone.
+  // Fewer sweeps?  Worth a search only where a sweep costs about what the search does: budget = the label changes that
+  // fit into ~3 sweep times of one host thread (2 x state bytes at 5.5 TB/s, ~10 ns per change: 2 M changes = ~20 ms for a
+  // 16-GiB state), hidden behind the GPU whenever circuits are submitted back to back, paid once per circuit with the plan
+  // cache on.  QH_PLAN_SEARCH=0 switches it off, QH_PLAN_SEARCH_STEPS pins the budget.
+  // Round 6: the search is Planner::search_levels (nested cuts instead of tiles), and it runs as a PORTFOLIO: for the wave-bit
+  // count the skeletons chose and for two wave bits (a tile of 13 bits instead of 12), every K from three below the greedy
+  // count (never below what the qubit count allows) up to one below it, each on two generator streams -- one host thread
+  // each, so the wall time is ONE budget whatever fails (the search for the K that does not exist always does).  The outcome
+  // does not depend on the threads' timing: per (wave bits, K) the stream that needed the fewest label changes wins, a
+  // stream only stops early when another one of the same (wave bits, K) has succeeded with fewer changes or a smaller K of
+  // the same wave bits has (its result is then never looked at).  Candidates are compared by PREDICTED TIME
+  // (plan_predicted_ms).  Eight supremacy-30 instances: greedy 5 6 6 6 7 7 6 6 sweeps, round 5's tile search 4 5 5 5 6 6 5 5,
+  // its round-6 form 4 4 5 5 5 6 5 5, now 4 4 4 4 4 5 4 4 -- the minimum for each under 13-bit tiles (integer program,
+  // profiles/r06/level_search.txt).
   uint64_t dense_bits = 0;
   for (const GateRec &q : queue) if (q.tgt >= 0 && q.tgt < nloc && !plan_diag(q.g, q.tgt)) dense_bits |= 1ull << q.tgt;
   const int lane_low = bw == 128 ? 3 : 4;
@@ -2037,53 +2118,63 @@ inline PlanResult plan_best(const std::vector<GateRec> &queue, int nloc, uint64_
   std::vector<PlanResult> cands;
   if (best_n >= 3 && env_flag("QH_PLAN_SEARCH", true)) {
     const double sweep_us = 2.0 * (double)(bw == 128 ? 16 : 8) * (double)(1ull << nloc) / 5.5e6;
-    uint64_t budget = std::min<uint64_t>((uint64_t)(sweep_us * 650.0), 8000000);      // ~1.6 sweep times of host work, at most ~20 ms
+    uint64_t budget = std::min<uint64_t>((uint64_t)(sweep_us * 320.0), 2500000);
     if (const char *e = getenv("QH_PLAN_SEARCH_STEPS")) budget = strtoull(e, nullptr, 10);
-    const bool again = env_flag("QH_PLAN_SEARCH_AGAIN", true);
+    struct Task {
+      int wb;
+      size_t K;
+      uint64_t stream, used = 0;
+      bool ok = false;
+      std::vector<std::vector<int>> tiles;
+    };
+    std::vector<Task> tasks;
+    std::atomic<uint64_t> stop_at[kMaxWaveBits + 1][9];       // per (wave bits, K): the fewest label changes a stream succeeded with
+    for (auto &row : stop_at) for (auto &x : row) x.store(~0ull);
+    const int streams = std::max(1, std::min(4, env_int("QH_PLAN_SEARCH_STREAMS", 2)));
+    const size_t nmovable = (size_t)popc(dense_bits >> lane_low);
+    for (int pass = 0; pass < 2 && budget >= 5000; ++pass) {
+      const int wb = pass == 0 ? best_wb : 2;
+      if (pass == 1 && (best_wb != 1 || !env_flag("QH_PLAN_SEARCH_WB2", true) || far_of[2] || (only_wb >= 0 && only_wb != 2) ||
+                        best_n < 4 || n_of[2] == 0)) break;
+      const size_t cap = (size_t)(cap0 + wb), greedy = n_of[wb];
+      const size_t kmin = std::max<size_t>({2, (nmovable + cap - 1) / cap, greedy > 3 ? greedy - 3 : 0});
+      for (size_t K = kmin; K + 1 <= greedy && K <= 8; ++K)
+        for (int s = 0; s < streams; ++s) tasks.push_back(Task{wb, K, (uint64_t)(s + 1)});
+    }
+    auto run = [&](Task &t) {
+      // (a smaller K of the same wave bits already found: this K's answer will not be used)
+      for (size_t k = 2; k < t.K; ++k) if (stop_at[t.wb][k].load(std::memory_order_relaxed) != ~0ull) return;
+      Planner p(nloc, shard, bw, max_rb, split_lanes, t.wb, allow_relayout, keep_ghosts);
+      // the wave-bit count the skeletons preferred searches on half a budget (where it has a tiling it is found early:
+      // supremacy-30 seeds 0 and 1 with 12-bit tiles after 0.3-0.5 M label changes)
+      t.ok = p.search_levels(queue, t.K, t.wb == best_wb && best_wb != 2 ? budget / 2 : budget, t.stream, &t.tiles, &t.used, &stop_at[t.wb][t.K]);
+    };
+    if (tasks.size() == 1 || !env_flag("QH_PLAN_SEARCH_THREADS", true)) {
+      for (Task &t : tasks) run(t);
+    } else if (!tasks.empty()) {
+      std::vector<std::thread> th;
+      th.reserve(tasks.size());
+      for (Task &t : tasks) th.emplace_back(run, std::ref(t));
+      for (std::thread &x : th) x.join();
+    }
     size_t target = best_n;           // sweeps of the best plan known so far
-    // ALL searches of a flush draw from one pool of 1.5 budgets (~15 ms of host time for a 16-GiB state at most, usually a few:
-    // a search that succeeds stops early): planning must stay below the time the GPU needs for the previous flush, behind which
-    // it hides when circuits are submitted back to back (bench.py plans every step from scratch)
-    uint64_t pool = budget + budget / 2;
     for (int pass = 0; pass < 2; ++pass) {
       const int wb = pass == 0 ? best_wb : 2;
-      if (pass == 1 && best_wb == 2) break;          // (the first search was the two-wave-bit one)
-      if (budget < 20000 || pool < 20000) break;
-      if (wb != best_wb && (best_wb != 1 || !env_flag("QH_PLAN_SEARCH_WB2", true) || far_of[2] || (only_wb >= 0 && only_wb != 2) ||
-                            target < 4 || n_of[2] == 0)) continue;
-      const int cap = cap0 + wb;
-      std::vector<uint64_t> start;
-      size_t n = 0;
-      bool far = false;
-      Planner(nloc, shard, bw, max_rb, split_lanes, wb, allow_relayout, keep_ghosts).skeleton(queue, &n, &far, &start);
-      std::vector<std::vector<int>> tiles;
-      bool found = false;
-      // every qubit must be visited at least once: K tiles of `cap` bits
-      while (start.size() >= 3 && popc(dense_bits >> lane_low) <= (int)(start.size() - 1) * cap) {
-        std::vector<std::vector<int>> fewer;
-        uint64_t used = 0;
-        const bool ok = pool >= 20000 &&
-            Planner(nloc, shard, bw, max_rb, split_lanes, wb, allow_relayout, keep_ghosts).search_tiles(queue, start, std::min(budget, pool), &fewer, &used);
-        pool -= std::min(pool, used);
-        if (env_flag("QH_PLAN_SEARCH_LOG", false))
-          fprintf(stderr, "[qh plan search] wave bits %d: %zu -> %zu tiles %s after %llu visits (budget %llu, pool left %llu)\n", wb, start.size(),
-                  start.size() - 1, ok ? "found" : "not found", (unsigned long long)used, (unsigned long long)budget, (unsigned long long)pool);
-        if (!ok) break;
-        tiles.swap(fewer);
-        found = true;
-        if (!again || (pass == 0 && wb != 2)) break;   // (repeated on the two-wave-bit chain only: with one wave bit a second search never found anything)
-        start.clear();
-        for (const auto &t : tiles) {
-          uint64_t m = 0;
-          for (int b : t) m |= 1ull << b;
-          start.push_back(m);
-        }
+      if (pass == 1 && best_wb == 2) break;
+      // per wave-bit count: the smallest K that was found, and of its streams the one with the fewest label changes
+      const Task *win = nullptr;
+      for (const Task &t : tasks) {
+        if (t.wb != wb || !t.ok) continue;
+        if (!win || t.K < win->K || (t.K == win->K && (t.used < win->used || (t.used == win->used && t.stream < win->stream)))) win = &t;
       }
-      if (!found || tiles.size() >= target) continue;
+      if (env_flag("QH_PLAN_SEARCH_LOG", false))
+        fprintf(stderr, "[qh plan search] wave bits %d: greedy %zu, %s %zu tiles (budget %llu label changes, %zu tasks)\n", wb, n_of[wb],
+                win ? "found" : "nothing below", win ? win->K : n_of[wb], (unsigned long long)budget, tasks.size());
+      if (!win || win->K >= target) continue;
       Planner forced(nloc, shard, bw, max_rb, split_lanes, wb, allow_relayout, keep_ghosts);
-      forced.set_tiles(tiles);
+      forced.set_tiles(win->tiles);
       PlanResult pr = forced.plan(queue);
-      if (pr.sweeps.size() < target && !plan_has_far_tile(pr)) {     // (the model ignores relabelling: check)
+      if (pr.sweeps.size() < target && !plan_has_far_tile(pr)) {     // (the model ignores relabelling and tile positions: check)
         target = pr.sweeps.size();
         cands.push_back(std::move(pr));
       }

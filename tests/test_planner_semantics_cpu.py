@@ -230,30 +230,36 @@ def test_every_rank_plans_the_same_geometry(oracle, monkeypatch, env):
     assert err < 1e-11, (env, case, n, gshard, err)
 
 
-def test_tile_search_saves_a_sweep_and_keeps_the_amplitudes(oracle, monkeypatch):
-  """planner.h search_tiles: for layered circuits the greedy tile choice is not the best one; a budgeted local search
-  (deterministic, counted in gate visits) looks for one sweep less.  BASELINE config 3 (30 qubits, depth 20, seed 0):
-  5 -> 4 sweeps; the plans it produces must of course still compute the circuit (here at 16 qubits, through NumPy)."""
+def test_level_search_saves_sweeps_and_keeps_the_amplitudes(oracle, monkeypatch):
+  """planner.h search_levels: for layered circuits the greedy tile choice is not the best one; a budgeted local search over the
+  nested cuts of the circuit (deterministic, counted in label changes, a portfolio of host threads) looks for fewer sweeps.
+  BASELINE config 3 (30 qubits, depth 20): seeds 0-3 run in 4 sweeps (greedy 5 6 6 6), seed 5 in 5 (greedy 8 with one wave bit, 7 with two; an integer
+  program says that is its minimum, profiles/r06/level_search.txt); the plans it produces must of course still compute the
+  circuit (here at 15-17 qubits, through NumPy)."""
   from tests.test_planner_cpu import _plan
-  ops, g8 = workloads.supremacy_stream(30, 20, seed=0).arrays()
+  monkeypatch.setenv('QH_PLAN_SEARCH_STEPS', '2000000')      # (pinned: the default scales with the sweep time)
+  streams = {seed: workloads.supremacy_stream(30, 20, seed=seed).arrays() for seed in (0, 1, 2, 3, 5)}
+  ops, g8 = streams[0]
   monkeypatch.setenv('QH_PLAN_SEARCH', '0')
-  greedy = len(_plan(30, ops, g8)['sweeps'])
+  greedy = [len(_plan(30, *streams[seed])['sweeps']) for seed in (0, 1, 2, 3, 5)]
   monkeypatch.setenv('QH_PLAN_SEARCH', '1')
-  searched = _plan(30, ops, g8)
-  assert greedy == 5 and len(searched['sweeps']) == 4
-  assert sum(s['gates'] for s in searched['sweeps']) + searched['noop_gates'] == len(ops)
-  # the budget is spent on independent attempts (walks are heavy-tailed): seed 1 gets 6 -> 5, which one long walk misses
-  ops1, g81 = workloads.supremacy_stream(30, 20, seed=1).arrays()
-  monkeypatch.setenv('QH_PLAN_SEARCH_STEPS', '4000000')      # (pinned: the default scales with the sweep time)
+  searched = {seed: _plan(30, *streams[seed]) for seed in (0, 1, 2, 3, 5)}
+  assert greedy == [5, 6, 6, 6, 8] and [len(searched[s]['sweeps']) for s in (0, 1, 2, 3, 5)] == [4, 4, 4, 4, 5]
+  for seed, p in searched.items():
+    assert sum(s['gates'] for s in p['sweeps']) + p['noop_gates'] == len(streams[seed][0])
+  # twelve-bit tiles (one wave bit) only: seeds 0 and 1 have a 4-sweep tiling there too, seed 2 has none (five)
   monkeypatch.setenv('QH_PLAN_SEARCH_WB2', '0')
-  assert len(_plan(30, ops1, g81)['sweeps']) == 5
-  # round 6: the search also runs with two wave bits (13-bit tiles) when that can still save a sweep: seed 1 6 -> 5 -> 4
+  monkeypatch.setenv('QH_PLAN_ONLY_WB', '1')
+  assert [len(_plan(30, *streams[s])['sweeps']) for s in (1, 2)] == [4, 5]
   monkeypatch.delenv('QH_PLAN_SEARCH_WB2')
-  p1 = _plan(30, ops1, g81)
-  assert len(p1['sweeps']) == 4 and any(len(s['wavepos']) == 2 for s in p1['sweeps'])
-  assert sum(s['gates'] for s in p1['sweeps']) + p1['noop_gates'] == len(ops1)
-  again = _plan(30, ops, g8)                                 # deterministic: same circuit, same tiles
-  assert [s['regpos'] for s in again['sweeps']] == [s['regpos'] for s in _plan(30, ops, g8)['sweeps']]
+  monkeypatch.delenv('QH_PLAN_ONLY_WB')
+  # deterministic: same circuit, same tiles -- with the streams on host threads and one after the other
+  again = _plan(30, *streams[2])
+  assert [s['regpos'] for s in again['sweeps']] == [s['regpos'] for s in searched[2]['sweeps']]
+  monkeypatch.setenv('QH_PLAN_SEARCH_THREADS', '0')
+  serial = _plan(30, *streams[2])
+  assert [(s['regpos'], s['lanehi'], s['wavepos']) for s in serial['sweeps']] == [(s['regpos'], s['lanehi'], s['wavepos']) for s in again['sweeps']]
+  monkeypatch.delenv('QH_PLAN_SEARCH_THREADS')
   monkeypatch.setenv('QH_PLAN_SEARCH_STEPS', '4000000')      # (small states get no budget by default: a sweep is cheap there)
   rng = np.random.default_rng(16)
   for n, seed in ((16, 0), (17, 3), (15, 1)):
