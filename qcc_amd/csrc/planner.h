@@ -14,7 +14,6 @@
 #include <stdint.h>
 
 #include <algorithm>
-#include <atomic>
 #include <cassert>
 #include <cmath>
 #include <cstdio>
@@ -372,9 +371,7 @@ class Planner {
   // seeds 2 3 4 6 7 in 2-20 ms where the tile search had found none in 2 x 10^9 gate visits (an integer program says
   // they exist, and that seed 5 needs five: profiles/r06/level_search.txt).  Deterministic (generator seeded by
   // `stream`, budget counted in label changes, canonical bit numbers): the ranks of a sharded state find the same tiles.
-  // `stop_at` (optional, shared between the streams of one (wave bits, K)): a stream gives up once it has spent more
-  // label changes than another stream needed to succeed -- the winner is the stream with the fewest, whatever the
-  // threads' timing was.  Returns true and the tiles (bit numbering of the start of the flush).
+  // Returns true and the tiles (bit numbering of the start of the flush).
   void canonical_records(const std::vector<GateRec> &pending, std::vector<PassRec> *rec0, int back[64], uint64_t *movable) {
     // CANONICAL bit numbers -- index bits above the 128-byte line renumbered in the order the queue first uses them -- so
     // that the same circuit gets the same walk, and the same answer, whatever layout earlier relayout sweeps have left
@@ -406,8 +403,7 @@ class Planner {
     *movable = dense_used & ~always;
   }
   bool search_levels(const std::vector<GateRec> &queue, size_t K, uint64_t change_budget, uint64_t stream,
-                     std::vector<std::vector<int>> *tiles_out, uint64_t *changes_used = nullptr,
-                     std::atomic<uint64_t> *stop_at = nullptr) {
+                     std::vector<std::vector<int>> *tiles_out, uint64_t *changes_used = nullptr) {
     if (changes_used) *changes_used = 0;
     if (K < 2 || K > 8) return false;
     std::vector<GateRec> pending;
@@ -523,7 +519,7 @@ class Planner {
       long best_key = cost(&best_over);
       over = best_over;
       for (long it = 0; it < kRestart && over > 0; ++it) {
-        if (changes > change_budget || (stop_at && changes > stop_at->load(std::memory_order_relaxed))) goto out;
+        if (changes > change_budget) goto out;
         // a circuit without a K-sweep tiling shows it early (supremacy-30 with K = 3: the overflow never drops below 5; every
         // instance that has one is at 1-4 after 400 iterations): the first walk ends the search then
         if (walk == 0 && it == 400 && best_over > 4) goto out;
@@ -563,14 +559,7 @@ class Planner {
     }
   out:
     if (changes_used) *changes_used = changes;
-    if (env_flag("QH_PLAN_SEARCH_LOG", false))
-      fprintf(stderr, "[qh plan search]   K=%zu cap %d stream %llu: %s after %llu label changes\n", K, cap, (unsigned long long)stream,
-              found ? "found" : "not found", (unsigned long long)changes);
     if (!found) return false;
-    if (stop_at) {      // (atomic minimum)
-      uint64_t cur = stop_at->load(std::memory_order_relaxed);
-      while (changes < cur && !stop_at->compare_exchange_weak(cur, changes, std::memory_order_relaxed)) {}
-    }
     tiles_out->clear();
     for (size_t s = 0; s < K; ++s) {
       std::vector<int> b;
@@ -2039,18 +2028,22 @@ inline double sweep_op_energy_nj(const SweepPlan &sp) {
   return e;
 }
 
-// Predicted time of a plan in ms.  A sweep is a stream of 2 x (state bytes) through HBM beside its op stream, under the
-// socket's power limit: (fixed energy of the stream + op energy) / 1 400 W, never faster than the stream alone.  The two
-// constants are the round-5 measurements of a 2^30-amplitude complex128 state (profiles/r05): three QFT sweeps of 2.1 J of
-// ops each take 5.74 ms, four supremacy sweeps of 3.9 J each 7.0-7.2 ms  =>  ~6.0 J fixed per sweep; an op-light sweep
-// streams in 5.4 ms.  Both scale with the bytes swept (fixed bits fold the tile count; complex64 moves half).
+// Predicted time of a plan in ms.  A sweep is a stream of 2 x (state bytes) through HBM beside its op stream; round 6 fitted
+// the per-sweep times of 159 sweeps of 36 supremacy-30 plans (2^30 amplitudes, complex128; profiles/r06/level_search.txt) against
+// the op energy of the price list above: flat at the stream's own time up to ~4 000 instructions (~3 J of ops) per tile, then
+// +0.74 ms per 1 000 instructions = ~1.0 ms per Joule of ops -- steeper than energy / 1 400 W (0.71 ms per J): a heavy sweep
+// is bound by VALU issue (a wave-instruction on FP64 keeps its SIMD 4 cycles, 512 tiles per SIMD: 8 000 instructions per tile
+// = 8.2 ms at 2 GHz) before it is bound by the socket's power -- so the cost of a plan is CONVEX in how its ops are spread over
+// its sweeps (a light sweep cannot go below the stream, a heavy one pays the steeper rate).  The stream's own time: 5.5 ms for
+// tiles of up to one wave bit (the QFT's sweeps: 5.45-5.6), 6.0 ms for four-wave workgroups.  Both scale with the bytes swept
+// (fixed bits fold the tile count; complex64 moves half).  Residual of the fit: 0.6 ms per sweep (placement, gather geometry).
 inline double plan_predicted_ms(const PlanResult &pr, int nloc, int bw) {
   double ms = 0;
   for (const SweepPlan &sp : pr.sweeps) {
     const double scale = (double)sp.swept_bytes / (2.0 * 16.0 * (double)(1ull << 30));
     const double e_ops_j = sweep_op_energy_nj(sp) * (double)sp.ntiles * 1e-9;
-    const double floor_ms = 5.4 * scale, fixed_j = 6.0 * scale;
-    ms += std::max(floor_ms, (fixed_j + e_ops_j) / 1400.0 * 1e3);
+    const double floor_ms = (sp.nwave >= 2 ? 6.0 : 5.5) * scale;
+    ms += std::max(floor_ms, 3.0 * scale + 0.99 * e_ops_j);
   }
   (void)nloc; (void)bw;
   return ms;
@@ -2098,39 +2091,37 @@ inline PlanResult plan_best(const std::vector<GateRec> &queue, int nloc, uint64_
   }
   Planner chosen(nloc, shard, bw, max_rb, split_lanes, best_wb, allow_relayout, keep_ghosts);
   // Fewer sweeps?  Worth a search only where a sweep costs about what the search does: budget = the label changes that
-  // fit into ~3 sweep times of one host thread (2 x state bytes at 5.5 TB/s, ~10 ns per change: 2 M changes = ~20 ms for a
-  // 16-GiB state), hidden behind the GPU whenever circuits are submitted back to back, paid once per circuit with the plan
-  // cache on.  QH_PLAN_SEARCH=0 switches it off, QH_PLAN_SEARCH_STEPS pins the budget.
+  // fit into ~3 sweep times of one host thread (2 x state bytes at 5.5 TB/s, ~5 ns per change on the GPU box's host: 4 M
+  // changes = ~20 ms for a 16-GiB state), hidden behind the GPU whenever circuits are submitted back to back, paid once per
+  // circuit with the plan cache on.  QH_PLAN_SEARCH=0 switches it off, QH_PLAN_SEARCH_STEPS pins the budget.
   // Round 6: the search is Planner::search_levels (nested cuts instead of tiles), and it runs as a PORTFOLIO: for the wave-bit
   // count the skeletons chose and for two wave bits (a tile of 13 bits instead of 12), every K from three below the greedy
-  // count (never below what the qubit count allows) up to one below it, each on two generator streams -- one host thread
-  // each, so the wall time is ONE budget whatever fails (the search for the K that does not exist always does).  The outcome
-  // does not depend on the threads' timing: per (wave bits, K) the stream that needed the fewest label changes wins, a
-  // stream only stops early when another one of the same (wave bits, K) has succeeded with fewer changes or a smaller K of
-  // the same wave bits has (its result is then never looked at).  Candidates are compared by PREDICTED TIME
-  // (plan_predicted_ms).  Eight supremacy-30 instances: greedy 5 6 6 6 7 7 6 6 sweeps, round 5's tile search 4 5 5 5 6 6 5 5,
-  // its round-6 form 4 4 5 5 5 6 5 5, now 4 4 4 4 4 5 4 4 -- the minimum for each under 13-bit tiles (integer program,
-  // profiles/r06/level_search.txt).
+  // count (never below what the qubit count allows) up to one below it, each on four generator streams -- one host thread
+  // per task, so the wall time is ONE budget whatever fails (the search for the K that does not exist always does).  A task
+  // that finds tiles builds its plan and prices it (plan_predicted_ms: stream energy + op energy under the socket's power
+  // limit); the cheapest plan wins -- tilings of one circuit differ by 5-10 % in what their ops cost --, the greedy plan
+  // included.  Every task is deterministic by itself, so the outcome does not depend on the threads' timing.  Twelve
+  // supremacy-30 instances (seeds 0-11): greedy 5 6 6 6 7 7 6 6 5 6 6 6 sweeps, the tile search 4 4 5 5 5 6 5 5 4 5 5 5, now
+  // 4 4 4 4 5 5 4 4 4 4 5 4 (an integer program: 4 is feasible for all but seeds 5 and 10; seed 4 is the one the budget
+  // misses; profiles/r06/level_search.txt); GPU time of the sweeps -6 % on average, -19 % at best.
   uint64_t dense_bits = 0;
   for (const GateRec &q : queue) if (q.tgt >= 0 && q.tgt < nloc && !plan_diag(q.g, q.tgt)) dense_bits |= 1ull << q.tgt;
   const int lane_low = bw == 128 ? 3 : 4;
   const int cap0 = (kLaneBits - lane_low) + std::min({max_rb, max_reg_bits(bw), nloc - kLaneBits});
-  std::vector<PlanResult> cands;
   if (best_n >= 3 && env_flag("QH_PLAN_SEARCH", true)) {
     const double sweep_us = 2.0 * (double)(bw == 128 ? 16 : 8) * (double)(1ull << nloc) / 5.5e6;
-    uint64_t budget = std::min<uint64_t>((uint64_t)(sweep_us * 320.0), 2500000);
+    uint64_t budget = std::min<uint64_t>((uint64_t)(sweep_us * 640.0), 5000000);
     if (const char *e = getenv("QH_PLAN_SEARCH_STEPS")) budget = strtoull(e, nullptr, 10);
     struct Task {
       int wb;
       size_t K;
       uint64_t stream, used = 0;
-      bool ok = false;
-      std::vector<std::vector<int>> tiles;
+      bool ok = false, planned = false;
+      double ms = 0;
+      PlanResult pr;
     };
     std::vector<Task> tasks;
-    std::atomic<uint64_t> stop_at[kMaxWaveBits + 1][9];       // per (wave bits, K): the fewest label changes a stream succeeded with
-    for (auto &row : stop_at) for (auto &x : row) x.store(~0ull);
-    const int streams = std::max(1, std::min(4, env_int("QH_PLAN_SEARCH_STREAMS", 2)));
+    const int streams = std::max(1, std::min(8, env_int("QH_PLAN_SEARCH_STREAMS", 4)));
     const size_t nmovable = (size_t)popc(dense_bits >> lane_low);
     for (int pass = 0; pass < 2 && budget >= 5000; ++pass) {
       const int wb = pass == 0 ? best_wb : 2;
@@ -2139,57 +2130,50 @@ inline PlanResult plan_best(const std::vector<GateRec> &queue, int nloc, uint64_
       const size_t cap = (size_t)(cap0 + wb), greedy = n_of[wb];
       const size_t kmin = std::max<size_t>({2, (nmovable + cap - 1) / cap, greedy > 3 ? greedy - 3 : 0});
       for (size_t K = kmin; K + 1 <= greedy && K <= 8; ++K)
-        for (int s = 0; s < streams; ++s) tasks.push_back(Task{wb, K, (uint64_t)(s + 1)});
+        for (int s = 0; s < streams; ++s) { tasks.emplace_back(); tasks.back().wb = wb; tasks.back().K = K; tasks.back().stream = (uint64_t)(s + 1); }
     }
     auto run = [&](Task &t) {
-      // (a smaller K of the same wave bits already found: this K's answer will not be used)
-      for (size_t k = 2; k < t.K; ++k) if (stop_at[t.wb][k].load(std::memory_order_relaxed) != ~0ull) return;
       Planner p(nloc, shard, bw, max_rb, split_lanes, t.wb, allow_relayout, keep_ghosts);
-      // the wave-bit count the skeletons preferred searches on half a budget (where it has a tiling it is found early:
-      // supremacy-30 seeds 0 and 1 with 12-bit tiles after 0.3-0.5 M label changes)
-      t.ok = p.search_levels(queue, t.K, t.wb == best_wb && best_wb != 2 ? budget / 2 : budget, t.stream, &t.tiles, &t.used, &stop_at[t.wb][t.K]);
+      std::vector<std::vector<int>> tiles;
+      t.ok = p.search_levels(queue, t.K, budget, t.stream, &tiles, &t.used);
+      if (!t.ok) return;
+      Planner forced(nloc, shard, bw, max_rb, split_lanes, t.wb, allow_relayout, keep_ghosts);
+      forced.set_tiles(tiles);
+      t.pr = forced.plan(queue);
+      t.planned = t.pr.sweeps.size() <= t.K && !plan_has_far_tile(t.pr);     // (the model ignores relabelling and tile positions: check)
+      if (t.planned) t.ms = plan_predicted_ms(t.pr, nloc, bw);
     };
-    if (tasks.size() == 1 || !env_flag("QH_PLAN_SEARCH_THREADS", true)) {
+    PlanResult greedy_plan;
+    if (tasks.empty() || !env_flag("QH_PLAN_SEARCH_THREADS", true)) {
       for (Task &t : tasks) run(t);
-    } else if (!tasks.empty()) {
+      greedy_plan = chosen.plan(queue);
+    } else {
       std::vector<std::thread> th;
       th.reserve(tasks.size());
       for (Task &t : tasks) th.emplace_back(run, std::ref(t));
+      greedy_plan = chosen.plan(queue);
       for (std::thread &x : th) x.join();
     }
-    size_t target = best_n;           // sweeps of the best plan known so far
-    for (int pass = 0; pass < 2; ++pass) {
-      const int wb = pass == 0 ? best_wb : 2;
-      if (pass == 1 && best_wb == 2) break;
-      // per wave-bit count: the smallest K that was found, and of its streams the one with the fewest label changes
-      const Task *win = nullptr;
-      for (const Task &t : tasks) {
-        if (t.wb != wb || !t.ok) continue;
-        if (!win || t.K < win->K || (t.K == win->K && (t.used < win->used || (t.used == win->used && t.stream < win->stream)))) win = &t;
-      }
-      if (env_flag("QH_PLAN_SEARCH_LOG", false))
-        fprintf(stderr, "[qh plan search] wave bits %d: greedy %zu, %s %zu tiles (budget %llu label changes, %zu tasks)\n", wb, n_of[wb],
-                win ? "found" : "nothing below", win ? win->K : n_of[wb], (unsigned long long)budget, tasks.size());
-      if (!win || win->K >= target) continue;
-      Planner forced(nloc, shard, bw, max_rb, split_lanes, wb, allow_relayout, keep_ghosts);
-      forced.set_tiles(win->tiles);
-      PlanResult pr = forced.plan(queue);
-      if (pr.sweeps.size() < target && !plan_has_far_tile(pr)) {     // (the model ignores relabelling and tile positions: check)
-        target = pr.sweeps.size();
-        cands.push_back(std::move(pr));
-      }
+    // every task is deterministic by itself (its generator, its budget in label changes); the winner is the plan with the
+    // smallest predicted time, ties by the order of the task list -- whatever the threads' timing was
+    const Task *win = nullptr;
+    double best_ms = plan_predicted_ms(greedy_plan, nloc, bw);
+    for (const Task &t : tasks)
+      if (t.planned && t.pr.sweeps.size() <= greedy_plan.sweeps.size() && t.ms < best_ms) { win = &t; best_ms = t.ms; }
+    if (env_flag("QH_PLAN_SEARCH_LOG", false)) {
+      for (const Task &t : tasks)
+        fprintf(stderr, "[qh plan search]   wave bits %d K=%zu stream %llu: %s after %llu label changes%s\n", t.wb, t.K, (unsigned long long)t.stream,
+                t.ok ? "found" : "not found", (unsigned long long)t.used,
+                t.planned ? (", " + std::to_string(t.pr.sweeps.size()) + " sweeps, predicted " + std::to_string(t.ms) + " ms").c_str() : "");
+      fprintf(stderr, "[qh plan search] greedy: %d wave bit(s), %zu sweeps, predicted %.2f ms; chosen: %s (%zu tasks, budget %llu label changes each)\n", best_wb,
+              greedy_plan.sweeps.size(), plan_predicted_ms(greedy_plan, nloc, bw),
+              win ? (std::to_string(win->pr.sweeps.size()) + " sweeps with " + std::to_string(win->wb) + " wave bit(s), predicted " + std::to_string(win->ms) + " ms").c_str() : "greedy",
+              tasks.size(), (unsigned long long)budget);
     }
+    if (win) return win->pr;
+    return greedy_plan;
   }
-  if (cands.empty()) return chosen.plan(queue);
-  if (cands.size() == 1 && !env_flag("QH_PLAN_COMPARE_GREEDY", false)) return std::move(cands[0]);
-  cands.push_back(chosen.plan(queue));
-  size_t best = 0;
-  double best_ms = 0;
-  for (size_t i = 0; i < cands.size(); ++i) {
-    const double ms = plan_predicted_ms(cands[i], nloc, bw);
-    if (i == 0 || ms < best_ms) { best = i; best_ms = ms; }
-  }
-  return std::move(cands[best]);
+  return chosen.plan(queue);
 }
 
 inline std::string plan_to_json(const std::vector<GateRec> &queue, int nloc, uint64_t shard, int bw = 128,
