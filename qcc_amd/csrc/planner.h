@@ -2043,7 +2043,9 @@ inline double plan_predicted_ms(const PlanResult &pr, int nloc, int bw) {
     const double scale = (double)sp.swept_bytes / (2.0 * 16.0 * (double)(1ull << 30));
     const double e_ops_j = sweep_op_energy_nj(sp) * (double)sp.ntiles * 1e-9;
     const double floor_ms = (sp.nwave >= 2 ? 6.0 : 5.5) * scale;
-    ms += std::max(floor_ms, 3.0 * scale + 0.99 * e_ops_j);
+    // (four-wave workgroups: two LDS exchanges and their barriers -- candidates of one circuit forced one by one,
+    // profiles/r06/level_search.txt: tilings with two wave bits run 0.2-0.4 ms per sweep above those with one at equal op energy)
+    ms += std::max(floor_ms, 3.0 * scale + 0.99 * e_ops_j) + (sp.nwave >= 2 ? 0.3 * scale : 0.0);
   }
   (void)nloc; (void)bw;
   return ms;
@@ -2096,7 +2098,7 @@ inline PlanResult plan_best(const std::vector<GateRec> &queue, int nloc, uint64_
   // circuit with the plan cache on.  QH_PLAN_SEARCH=0 switches it off, QH_PLAN_SEARCH_STEPS pins the budget.
   // Round 6: the search is Planner::search_levels (nested cuts instead of tiles), and it runs as a PORTFOLIO: for the wave-bit
   // count the skeletons chose and for two wave bits (a tile of 13 bits instead of 12), every K from three below the greedy
-  // count (never below what the qubit count allows) up to one below it, each on four generator streams -- one host thread
+  // count (never below what the qubit count allows) up to one below it, each on six generator streams -- one host thread
   // per task, so the wall time is ONE budget whatever fails (the search for the K that does not exist always does).  A task
   // that finds tiles builds its plan and prices it (plan_predicted_ms: stream energy + op energy under the socket's power
   // limit); the cheapest plan wins -- tilings of one circuit differ by 5-10 % in what their ops cost --, the greedy plan
@@ -2121,15 +2123,16 @@ inline PlanResult plan_best(const std::vector<GateRec> &queue, int nloc, uint64_
       PlanResult pr;
     };
     std::vector<Task> tasks;
-    const int streams = std::max(1, std::min(8, env_int("QH_PLAN_SEARCH_STREAMS", 4)));
+    const int streams = std::max(1, std::min(8, env_int("QH_PLAN_SEARCH_STREAMS", 6)));
     const size_t nmovable = (size_t)popc(dense_bits >> lane_low);
-    for (int pass = 0; pass < 2 && budget >= 5000; ++pass) {
-      const int wb = pass == 0 ? best_wb : 2;
-      if (pass == 1 && (best_wb != 1 || !env_flag("QH_PLAN_SEARCH_WB2", true) || far_of[2] || (only_wb >= 0 && only_wb != 2) ||
-                        best_n < 4 || n_of[2] == 0)) break;
+    for (int wb : {1, 2, 0}) {
+      // the wave-bit count the skeletons chose, and one and two wave bits (tiles of 12 and 13 bits) wherever they can save a sweep
+      if (budget < 5000) break;
+      if (wb != best_wb && (wb == 0 || far_of[wb] || n_of[wb] == 0 || best_n < 4 || (wb == 2 && !env_flag("QH_PLAN_SEARCH_WB2", true)))) continue;
+      if (only_wb >= 0 && wb != only_wb) continue;
       const size_t cap = (size_t)(cap0 + wb), greedy = n_of[wb];
       const size_t kmin = std::max<size_t>({2, (nmovable + cap - 1) / cap, greedy > 3 ? greedy - 3 : 0});
-      for (size_t K = kmin; K + 1 <= greedy && K <= 8; ++K)
+      for (size_t K = kmin; K + 1 <= greedy && K + 1 <= best_n + 1 && K <= 8; ++K)
         for (int s = 0; s < streams; ++s) { tasks.emplace_back(); tasks.back().wb = wb; tasks.back().K = K; tasks.back().stream = (uint64_t)(s + 1); }
     }
     auto run = [&](Task &t) {
@@ -2160,9 +2163,12 @@ inline PlanResult plan_best(const std::vector<GateRec> &queue, int nloc, uint64_
     double best_ms = plan_predicted_ms(greedy_plan, nloc, bw);
     for (const Task &t : tasks)
       if (t.planned && t.pr.sweeps.size() <= greedy_plan.sweeps.size() && t.ms < best_ms) { win = &t; best_ms = t.ms; }
+    if (const int pick = env_int("QH_PLAN_SEARCH_PICK", -1); pick >= 0) {      // (probe: the pick-th task of the list, if it has a plan -- tools/probes/r06_candidates.sh)
+      if ((size_t)pick < tasks.size() && tasks[pick].planned) win = &tasks[pick];
+    }
     if (env_flag("QH_PLAN_SEARCH_LOG", false)) {
       for (const Task &t : tasks)
-        fprintf(stderr, "[qh plan search]   wave bits %d K=%zu stream %llu: %s after %llu label changes%s\n", t.wb, t.K, (unsigned long long)t.stream,
+        fprintf(stderr, "[qh plan search]   task %d: wave bits %d K=%zu stream %llu: %s after %llu label changes%s\n", (int)(&t - &tasks[0]), t.wb, t.K, (unsigned long long)t.stream,
                 t.ok ? "found" : "not found", (unsigned long long)t.used,
                 t.planned ? (", " + std::to_string(t.pr.sweeps.size()) + " sweeps, predicted " + std::to_string(t.ms) + " ms").c_str() : "");
       fprintf(stderr, "[qh plan search] greedy: %d wave bit(s), %zu sweeps, predicted %.2f ms; chosen: %s (%zu tasks, budget %llu label changes each)\n", best_wb,

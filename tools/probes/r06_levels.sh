@@ -13,7 +13,7 @@ for round in 1 2; do
       unset QCC_HIP_LIB
       if [ $v = old ]; then [ -f $R/_ab/libqcc_hip_r06a.so ] || continue; export QCC_HIP_LIB=$R/_ab/libqcc_hip_r06a.so; fi
       echo "## $v seed $seed round $round" >> $O/ab.txt
-      QH_SWEEP_TIMING=1 timeout 120 python tools/run_workload.py sup30s$seed 8 2>&1 | grep -E "step ms|'sweeps'|sweeps" | tail -3 >> $O/ab.txt
+      timeout 120 python tools/run_workload.py sup30s$seed 14 2>&1 | grep -E "step ms|'sweeps'" | tail -2 >> $O/ab.txt
     done
   done
 done
@@ -21,15 +21,18 @@ unset QCC_HIP_LIB
 python3 - <<'PY' | tee gpurun_out/r06lv/summary.txt
 import re, collections, statistics
 rows = collections.defaultdict(list)
+nsw = {}
 key = None
 for ln in open('gpurun_out/r06lv/ab.txt'):
     if ln.startswith('## '):
         p = ln.split(); key = (int(p[3]), p[1])
+    elif "'sweeps'" in ln:
+        nsw[key] = int(re.search(r"'sweeps': (\d+)", ln).group(1)) // 15
     elif 'step ms' in ln:
         v = [float(x) for x in ln.split('step ms')[1].split()]
-        rows[key].append((statistics.median(v[2:]), max(v[2:])))
+        rows[key].append((statistics.median(v[-5:]), max(v[-5:])))
 for k in sorted(rows):
-    print('seed', k[0], f'{k[1]:4s}', ' '.join(f'{x:.2f} (max {m:.2f})' for x, m in rows[k]), 'ms per circuit (median of steps 3..8, one figure per process)')
+    print('seed', k[0], f'{k[1]:4s}', nsw.get(k), 'sweeps', ' '.join(f'{x:.2f} (max {m:.2f})' for x, m in rows[k]), 'ms per circuit (median and maximum of the last 5 of 14 steps -- plan cache on: GPU time --, one figure per process)')
 PY
 python3 - <<'PY' | tee -a gpurun_out/r06lv/summary.txt
 import ctypes, json, os, sys, time
