@@ -2123,8 +2123,8 @@ inline PlanResult plan_best(const std::vector<GateRec> &queue, int nloc, uint64_
       PlanResult pr;
     };
     std::vector<Task> tasks;
-    const int streams = std::max(1, std::min(8, env_int("QH_PLAN_SEARCH_STREAMS", 6)));
     const size_t nmovable = (size_t)popc(dense_bits >> lane_low);
+    std::vector<std::pair<int, size_t>> shapes;       // (wave bits, K)
     for (int wb : {1, 2, 0}) {
       // the wave-bit count the skeletons chose, and one and two wave bits (tiles of 12 and 13 bits) wherever they can save a sweep
       if (budget < 5000) break;
@@ -2132,9 +2132,16 @@ inline PlanResult plan_best(const std::vector<GateRec> &queue, int nloc, uint64_
       if (only_wb >= 0 && wb != only_wb) continue;
       const size_t cap = (size_t)(cap0 + wb), greedy = n_of[wb];
       const size_t kmin = std::max<size_t>({2, (nmovable + cap - 1) / cap, greedy > 3 ? greedy - 3 : 0});
-      for (size_t K = kmin; K + 1 <= greedy && K + 1 <= best_n + 1 && K <= 8; ++K)
-        for (int s = 0; s < streams; ++s) { tasks.emplace_back(); tasks.back().wb = wb; tasks.back().K = K; tasks.back().stream = (uint64_t)(s + 1); }
+      for (size_t K = kmin; K + 1 <= greedy && K <= best_n && K <= 8; ++K) shapes.emplace_back(wb, K);
     }
+    // six generator streams per shape (one host thread each) -- fewer on a host with few cores (an unsharded handle only: the
+    // ranks of a sharded state must find the same plan whatever their hosts are); QH_PLAN_SEARCH_STREAMS pins it
+    int streams = 6;
+    if (const unsigned hw = std::thread::hardware_concurrency(); hw && !keep_ghosts && !shapes.empty())
+      streams = std::max(1, std::min(6, (int)(hw / shapes.size())));
+    streams = std::max(1, std::min(8, env_int("QH_PLAN_SEARCH_STREAMS", streams)));
+    for (const auto &sh : shapes)
+      for (int s = 0; s < streams; ++s) { tasks.emplace_back(); tasks.back().wb = sh.first; tasks.back().K = sh.second; tasks.back().stream = (uint64_t)(s + 1); }
     auto run = [&](Task &t) {
       Planner p(nloc, shard, bw, max_rb, split_lanes, t.wb, allow_relayout, keep_ghosts);
       std::vector<std::vector<int>> tiles;

@@ -238,6 +238,7 @@ def test_level_search_saves_sweeps_and_keeps_the_amplitudes(oracle, monkeypatch)
   circuit (here at 15-17 qubits, through NumPy)."""
   from tests.test_planner_cpu import _plan
   monkeypatch.setenv('QH_PLAN_SEARCH_STEPS', '2000000')      # (pinned: the default scales with the sweep time)
+  monkeypatch.setenv('QH_PLAN_SEARCH_STREAMS', '6')          # (pinned: a host with few cores gets fewer by default)
   streams = {seed: workloads.supremacy_stream(30, 20, seed=seed).arrays() for seed in (0, 1, 2, 3, 5)}
   ops, g8 = streams[0]
   monkeypatch.setenv('QH_PLAN_SEARCH', '0')
