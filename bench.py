@@ -459,7 +459,7 @@ def other_configs(device_index):
     ops, g8 = workloads.supremacy_stream(30, 20, seed=seed).arrays()
     out[f'config3_supremacy30_d20_seed{seed}'] = config_line(
         f'30-qubit supremacy.py random circuit, depth 20, random.seed({seed}) [BASELINE config 3, SURVEY 8(d) seeds 0-2]', 30, 128, ops, g8, 0,
-        device_index, 10, 3, 'same family as seed 0; the number of sweeps depends on the instance (DESIGN 4.4 tile search)')
+        device_index, 10, 3, 'same family as seed 0; the number of sweeps depends on the instance (DESIGN 4.7 level search: 4 for seeds 0-4, the minimum under 13-bit tiles)')
   ops, g8 = workloads.qft_stream(range(30)).arrays()
   out['qft30_complex64'] = config_line(
       '30-qubit QFT at the reference\'s default width complex64 (src/lib/tensor.py:28)', 30, 64, ops, g8,

@@ -59,7 +59,7 @@ def test_config3_supremacy_30q_depth20(seed):
 @pytest.mark.parametrize('seed', [0, 1])
 def test_config3_supremacy_28q_against_the_oracle(seed):
   """(seed 1: VERDICT r05 #4 -- SURVEY 8(d) names seeds 0, 1, 2; since round 6 these instances plan with two wave bits, 13-bit
-  tiles found by the repeated tile search, 4 sweeps.)  Config 3's circuit family against the CPU ORACLE at a size the host finishes in seconds (VERDICT r2, next #6:
+  tiles found by the level search, 4 sweeps.)  Config 3's circuit family against the CPU ORACLE at a size the host finishes in seconds (VERDICT r2, next #6:
   the 30-qubit run above is GPU-vs-GPU plus inverse; the largest oracle comparison of a random circuit was 20
   qubits).  supremacy.py:123-158,208-253 at 28 qubits, depth 20, random.seed(0): every gate through
   oracle/xgates_oracle.c's restatement of xgates.cc:23-67 on all host cores (2^28 amplitudes, 4 GiB), the fused

@@ -31,7 +31,7 @@ while time.time() - t0 < budget:
   n = int(rng.integers(10, 17))
   gshard = int(rng.integers(0, 4)) if rng.random() < 0.4 else 0
   if cases % 2 and os.environ.get('QH_PLAN_SEARCH_STEPS') is None:
-    os.environ['QH_PLAN_SEARCH_STEPS'] = '300000'        # the tile search too (small states get no budget by default)
+    os.environ['QH_PLAN_SEARCH_STEPS'] = '300000'        # the level search too (small states get no budget by default)
   n = max(n, 10 + gshard)
   # sharded cases: half of them with plenty of rank-dependent gates (ghosts on some ranks, planner.h)
   stream = (_shard_variant_stream(rng, n, int(rng.integers(10, 300)), gshard) if gshard and rng.random() < 0.5
