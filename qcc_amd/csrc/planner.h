@@ -2142,12 +2142,20 @@ inline PlanResult plan_best(const std::vector<GateRec> &queue, int nloc, uint64_
     streams = std::max(1, std::min(8, env_int("QH_PLAN_SEARCH_STREAMS", streams)));
     for (const auto &sh : shapes)
       for (int s = 0; s < streams; ++s) { tasks.emplace_back(); tasks.back().wb = sh.first; tasks.back().K = sh.second; tasks.back().stream = (uint64_t)(s + 1); }
+    // (the planners are made HERE: their constructors read the switches, and getenv stays out of the worker threads)
+    std::vector<Planner> searchers, planners;
+    searchers.reserve(tasks.size());
+    planners.reserve(tasks.size());
+    for (const Task &t : tasks) {
+      searchers.emplace_back(nloc, shard, bw, max_rb, split_lanes, t.wb, allow_relayout, keep_ghosts);
+      planners.emplace_back(nloc, shard, bw, max_rb, split_lanes, t.wb, allow_relayout, keep_ghosts);
+    }
     auto run = [&](Task &t) {
-      Planner p(nloc, shard, bw, max_rb, split_lanes, t.wb, allow_relayout, keep_ghosts);
+      const size_t i = (size_t)(&t - &tasks[0]);
       std::vector<std::vector<int>> tiles;
-      t.ok = p.search_levels(queue, t.K, budget, t.stream, &tiles, &t.used);
+      t.ok = searchers[i].search_levels(queue, t.K, budget, t.stream, &tiles, &t.used);
       if (!t.ok) return;
-      Planner forced(nloc, shard, bw, max_rb, split_lanes, t.wb, allow_relayout, keep_ghosts);
+      Planner &forced = planners[i];
       forced.set_tiles(tiles);
       t.pr = forced.plan(queue);
       t.planned = t.pr.sweeps.size() <= t.K && !plan_has_far_tile(t.pr);     // (the model ignores relabelling and tile positions: check)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 6: GPU fuzz of the round's final build (plan_best: second-wave-bit search, predicted-time objective): fused path vs oracle
+# round 6: GPU fuzz of the round's final build (plan_best: the level search as a portfolio of host threads, predicted-time choice): fused path vs oracle
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r06fuzz; mkdir -p $O
 cd $R
