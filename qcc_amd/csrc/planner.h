@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -2168,8 +2169,12 @@ inline PlanResult plan_best(const std::vector<GateRec> &queue, int nloc, uint64_
     } else {
       std::vector<std::thread> th;
       th.reserve(tasks.size());
-      for (Task &t : tasks) th.emplace_back(run, std::ref(t));
+      std::vector<Task *> inline_tasks;       // (a host that refuses another thread: the task runs here -- same answer, later)
+      for (Task &t : tasks) {
+        try { th.emplace_back(run, std::ref(t)); } catch (const std::system_error &) { inline_tasks.push_back(&t); }
+      }
       greedy_plan = chosen.plan(queue);
+      for (Task *t : inline_tasks) run(*t);
       for (std::thread &x : th) x.join();
     }
     // every task is deterministic by itself (its generator, its budget in label changes); the winner is the plan with the
