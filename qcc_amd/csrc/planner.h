@@ -403,6 +403,62 @@ class Planner {
     for (int b = 0; b < 64; ++b) if (canon[b] >= 0) back[canon[b]] = b;
     *movable = dense_used & ~always;
   }
+  // The dependency graph of the DENSE gates, as pass_fast / build_sweep order them: a dense gate follows the last dense
+  // gate on its target, the last dense gate on each of its control bits, and -- through every diagonal gate (or control)
+  // that touched its target since -- the last dense gates on the other bits of that gate; diagonal uses commute.
+  static void build_dag(const std::vector<PassRec> &rec0, std::vector<int> *node_bit, std::vector<std::vector<int>> *succ,
+                        std::vector<std::vector<int>> *pred) {
+    int last_dense[64];
+    std::vector<int> need[64];
+    for (int b = 0; b < 64; ++b) last_dense[b] = -1;
+    for (const PassRec &r : rec0) {
+      if (!r.dense_bits) {
+        for (uint64_t t = r.diag_bits; t; t &= t - 1) {
+          const int b = __builtin_ctzll(t);
+          for (uint64_t u = r.diag_bits & ~(1ull << b); u; u &= u - 1)
+            if (last_dense[__builtin_ctzll(u)] >= 0) need[b].push_back(last_dense[__builtin_ctzll(u)]);
+        }
+        continue;
+      }
+      const int v = (int)node_bit->size(), tb = r.tgt;
+      node_bit->push_back(tb);
+      succ->emplace_back();
+      pred->emplace_back();
+      std::vector<int> ps;
+      if (last_dense[tb] >= 0) ps.push_back(last_dense[tb]);
+      for (int u : need[tb]) ps.push_back(u);
+      for (uint64_t t = r.diag_bits; t; t &= t - 1) if (last_dense[__builtin_ctzll(t)] >= 0) ps.push_back(last_dense[__builtin_ctzll(t)]);
+      std::sort(ps.begin(), ps.end());
+      ps.erase(std::unique(ps.begin(), ps.end()), ps.end());
+      for (int u : ps) { (*succ)[u].push_back(v); (*pred)[v].push_back(u); }
+      need[tb].clear();
+      last_dense[tb] = v;
+      for (uint64_t t = r.diag_bits; t; t &= t - 1) need[__builtin_ctzll(t)].push_back(v);
+    }
+  }
+  // The object the level search works on, for tools/tiling_milp.py (QH_PLAN_DAG=1 adds it to qh_plan_json): the target bit of every
+  // dense gate (numbering of the flush's start), the dependency edges, the line bits every tile holds, the tile caps.
+  std::string dag_json(const std::vector<GateRec> &queue) {
+    std::vector<GateRec> pending;
+    std::vector<uint64_t> alg;
+    uint64_t noops = 0;
+    prepare(queue, &pending, &alg, &noops);
+    std::vector<PassRec> rec0;
+    int back[64];
+    uint64_t movable = 0;
+    canonical_records(pending, &rec0, back, &movable);
+    std::vector<int> node_bit;
+    std::vector<std::vector<int>> succ, pred;
+    build_dag(rec0, &node_bit, &succ, &pred);
+    std::string o = "{\"line_bits\":" + std::to_string(lane_low_) + ",\"cap_per_wave_bits\":[" + std::to_string(lane_hi_ + rb_cap_) + "," +
+                    std::to_string(lane_hi_ + rb_cap_ + 1) + "," + std::to_string(lane_hi_ + rb_cap_ + 2) + "],\"target_bit\":[";
+    for (size_t g = 0; g < node_bit.size(); ++g) o += (g ? "," : "") + std::to_string(back[node_bit[g]]);
+    o += "],\"edges\":[";
+    bool first = true;
+    for (size_t u = 0; u < succ.size(); ++u)
+      for (int v : succ[u]) { o += (first ? "[" : ",[") + std::to_string(u) + "," + std::to_string(v) + "]"; first = false; }
+    return o + "]}";
+  }
   bool search_levels(const std::vector<GateRec> &queue, size_t K, uint64_t change_budget, uint64_t stream,
                      std::vector<std::vector<int>> *tiles_out, uint64_t *changes_used = nullptr) {
     if (changes_used) *changes_used = 0;
@@ -418,40 +474,9 @@ class Planner {
     const uint64_t always = (1ull << lane_low_) - 1;
     const int cap = lane_hi_ + rb_cap_ + max_wave_;
     if ((size_t)popc(movable) > K * (size_t)cap) return false;       // not even room to visit every qubit once
-    // The dependency graph of the DENSE gates, as pass_fast / build_sweep order them: a dense gate follows the last dense
-    // gate on its target, the last dense gate on each of its control bits, and -- through every diagonal gate (or control)
-    // that touched its target since -- the last dense gates on the other bits of that gate; diagonal uses commute.
     std::vector<int> node_bit;
     std::vector<std::vector<int>> succ, pred;
-    {
-      int last_dense[64];
-      std::vector<int> need[64];
-      for (int b = 0; b < 64; ++b) last_dense[b] = -1;
-      for (const PassRec &r : rec0) {
-        if (!r.dense_bits) {
-          for (uint64_t t = r.diag_bits; t; t &= t - 1) {
-            const int b = __builtin_ctzll(t);
-            for (uint64_t u = r.diag_bits & ~(1ull << b); u; u &= u - 1)
-              if (last_dense[__builtin_ctzll(u)] >= 0) need[b].push_back(last_dense[__builtin_ctzll(u)]);
-          }
-          continue;
-        }
-        const int v = (int)node_bit.size(), tb = r.tgt;
-        node_bit.push_back(tb);
-        succ.emplace_back();
-        pred.emplace_back();
-        std::vector<int> ps;
-        if (last_dense[tb] >= 0) ps.push_back(last_dense[tb]);
-        for (int u : need[tb]) ps.push_back(u);
-        for (uint64_t t = r.diag_bits; t; t &= t - 1) if (last_dense[__builtin_ctzll(t)] >= 0) ps.push_back(last_dense[__builtin_ctzll(t)]);
-        std::sort(ps.begin(), ps.end());
-        ps.erase(std::unique(ps.begin(), ps.end()), ps.end());
-        for (int u : ps) { succ[u].push_back(v); pred[v].push_back(u); }
-        need[tb].clear();
-        last_dense[tb] = v;
-        for (uint64_t t = r.diag_bits; t; t &= t - 1) need[__builtin_ctzll(t)].push_back(v);
-      }
-    }
+    build_dag(rec0, &node_bit, &succ, &pred);
     const int ng = (int)node_bit.size();
     if (!ng) return false;
     std::vector<int> depth(ng, 0);
@@ -2207,7 +2232,10 @@ inline std::string plan_to_json(const std::vector<GateRec> &queue, int nloc, uin
                                 bool keep_ghosts = false) {
   if (nloc < kLaneBits + 2) return "{\"sweeps\":[],\"note\":\"state too small for sweeps\"}";
   PlanResult pr = plan_best(queue, nloc, shard, bw, max_rb, split_lanes, allow_relayout, keep_ghosts);
-  std::string s = "{\"noop_gates\":" + std::to_string(pr.noop_gates) + ",\"sweeps\":[";
+  std::string s = "{\"noop_gates\":" + std::to_string(pr.noop_gates);
+  if (env_flag("QH_PLAN_DAG", false))         // (tools/tiling_milp.py)
+    s += ",\"dag\":" + Planner(nloc, shard, bw, max_rb, split_lanes, 1, allow_relayout, keep_ghosts).dag_json(queue);
+  s += ",\"sweeps\":[";
   char buf[384];
   for (size_t i = 0; i < pr.sweeps.size(); ++i) {
     const SweepPlan &sp = pr.sweeps[i];
