@@ -41,8 +41,8 @@ PY
 }
 trace fused 6 $B                                    # 2 warm-up steps x 3 sweeps dropped
 trace sup30 8 python $R/tools/run_workload.py sup30 5      # first two circuits dropped
-trace sup30s1 8 python $R/tools/run_workload.py sup30s1 5  # (round 6: 4 sweeps with two wave bits)
-trace sup30s2 10 python $R/tools/run_workload.py sup30s2 5 # (5 sweeps)
+trace sup30s1 8 python $R/tools/run_workload.py sup30s1 5  # (round 6: 4 sweeps)
+trace sup30s2 8 python $R/tools/run_workload.py sup30s2 5  # (4 sweeps since the level search)
 trace qft30c64 6 python $R/tools/run_workload.py qft30c64 5
 trace qft33 6 python $R/tools/run_workload.py qft33 4
 trace grover34 9 python $R/tools/run_workload.py grover34 2     # the first iteration (9 sweeps) dropped
