@@ -11,6 +11,7 @@
 //
 // Pure host C++ (no HIP types): unit-tested on CPU through qh_plan_json.
 #pragma once
+#include <sched.h>
 #include <stdint.h>
 
 #include <algorithm>
@@ -2077,6 +2078,29 @@ inline double plan_predicted_ms(const PlanResult &pr, int nloc, int bw) {
   return ms;
 }
 
+// Host threads this process may really run side by side: the hardware's count, cut down by the scheduler affinity and by a
+// cgroup CPU quota (a container limited to a few cores still reports every core of its host).
+inline unsigned usable_cpus() {
+  unsigned n = std::thread::hardware_concurrency();
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof set, &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0 && (!n || (unsigned)c < n)) n = (unsigned)c; }
+  for (const char *path : {"/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"}) {
+    FILE *f = fopen(path, "r");
+    if (!f) continue;
+    long long quota = -1, period = 100000;
+    char word[32] = {0};
+    if (fscanf(f, "%31s %lld", word, &period) >= 1 && strcmp(word, "max") != 0) quota = atoll(word);
+    fclose(f);
+    if (strstr(path, "cfs_quota")) {      // cgroup v1: the period sits in its own file
+      period = 100000;
+      if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%lld", &period) != 1) period = 100000; fclose(g); }
+    }
+    if (quota > 0 && period > 0) { const unsigned q = (unsigned)std::max<long long>(1, quota / period); if (!n || q < n) n = q; }
+    break;
+  }
+  return n;
+}
+
 inline PlanResult plan_best(const std::vector<GateRec> &queue, int nloc, uint64_t shard, int bw, int max_rb,
                             bool split_lanes, bool allow_relayout = false, bool keep_ghosts = false) {
   if (getenv("QH_WAVE_BITS")) return Planner(nloc, shard, bw, max_rb, split_lanes, -1, allow_relayout, keep_ghosts).plan(queue);
@@ -2163,7 +2187,7 @@ inline PlanResult plan_best(const std::vector<GateRec> &queue, int nloc, uint64_
     // six generator streams per shape (one host thread each) -- fewer on a host with few cores (an unsharded handle only: the
     // ranks of a sharded state must find the same plan whatever their hosts are); QH_PLAN_SEARCH_STREAMS pins it
     int streams = 6;
-    if (const unsigned hw = std::thread::hardware_concurrency(); hw && !keep_ghosts && !shapes.empty())
+    if (const unsigned hw = usable_cpus(); hw && !keep_ghosts && !shapes.empty())
       streams = std::max(1, std::min(6, (int)(hw / shapes.size())));
     streams = std::max(1, std::min(8, env_int("QH_PLAN_SEARCH_STREAMS", streams)));
     for (const auto &sh : shapes)

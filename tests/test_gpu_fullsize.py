@@ -28,12 +28,13 @@ def _inverse(ops, g8):
 
 
 @pytest.mark.parametrize('seed', [0, 1, 2, 3, 4, 5])
-def test_config3_supremacy_30q_depth20(seed):
+def test_config3_supremacy_30q_depth20(seed, monkeypatch):
   """BASELINE config 3 at full size, SURVEY 8(d)'s seeds 0, 1, 2 (the bench line carries all three since round 6) and three
   more: the fused sweeps (4 4 4 4 4 5 of them since the level search, planner.h search_levels: the minimum under 13-bit
   tiles for each) against the per-gate kernels on sampled windows at 1e-10, and the inverse circuit through the fused path
   back to |0>."""
   n = 30
+  monkeypatch.setenv('QH_PLAN_SEARCH_STREAMS', '6')      # (the default follows the host's usable cores: pinned for the sweep counts below)
   ops, g8 = workloads.supremacy_stream(n, 20, seed=seed).arrays()
   if seed == 0:
     assert len(ops) == 342                    # BASELINE.md: 30 H, 117 V/Yroot, 80 T, 115 CZ
