@@ -411,6 +411,8 @@ def config_line(name, n, bw, ops, g8, init, device_index, steps, warmup, note, t
   return {'workload': name, 'qubits': n, 'dtype': 'f64' if bw == 128 else 'f32', 'gates_per_step': len(ops), 'steps': steps,
           'warmup': warmup, 'ms_per_step': wall / steps * 1e3,
           'median_ms_per_step': float(np.median(st['step_ms'])) if st['step_ms'] else None,
+          'step_ms_min_max': [float(min(st['step_ms'])), float(max(st['step_ms']))] if st['step_ms'] else None,
+          'first_step_ms': float(st['step_ms'][0]) if st['step_ms'] else None,      # (planning of the first timed step has no GPU work to hide behind)
           'event_ms_per_step': ev_ms / steps, 'gate_applies_per_s': len(ops) * steps / wall,
           'sweeps_per_step': st['sweeps'] / steps,
           'effective_GBps_algorithmic': st['bytes_algorithmic'] / wall / 1e9,
@@ -453,13 +455,13 @@ def other_configs(device_index):
   out = {}
   ops, g8 = workloads.supremacy_stream(30, 20, seed=0).arrays()
   out['config3_supremacy30_d20_seed0'] = config_line(
-      '30-qubit supremacy.py random circuit, depth 20, random.seed(0) [BASELINE config 3]', 30, 128, ops, g8, 0, device_index, 10, 3,
+      '30-qubit supremacy.py random circuit, depth 20, random.seed(0) [BASELINE config 3]', 30, 128, ops, g8, 0, device_index, 20, 5,
       'op-heavy sweeps: bound by the socket power limit, not by HBM -- op streams alone 1 284 W at 2.39 GHz, with the tile streams 1 391 W of 1 400 W at 1.92 GHz (DESIGN 4.5, profiles/r04/smi_trace_sup30_*.csv)', 'traffic_sup30.json')
   for seed in (1, 2):          # SURVEY 8(d) config 3 names seeds 0, 1, 2
     ops, g8 = workloads.supremacy_stream(30, 20, seed=seed).arrays()
     out[f'config3_supremacy30_d20_seed{seed}'] = config_line(
         f'30-qubit supremacy.py random circuit, depth 20, random.seed({seed}) [BASELINE config 3, SURVEY 8(d) seeds 0-2]', 30, 128, ops, g8, 0,
-        device_index, 10, 3, 'same family as seed 0; the number of sweeps depends on the instance (DESIGN 4.7 level search: 4 for seeds 0-4, the minimum under 13-bit tiles)')
+        device_index, 20, 5, 'same family as seed 0; the number of sweeps depends on the instance (DESIGN 4.7 level search: 4 for seeds 0-4, the minimum under 13-bit tiles)')
   ops, g8 = workloads.qft_stream(range(30)).arrays()
   out['qft30_complex64'] = config_line(
       '30-qubit QFT at the reference\'s default width complex64 (src/lib/tensor.py:28)', 30, 64, ops, g8,
