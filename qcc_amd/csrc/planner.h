@@ -2209,7 +2209,9 @@ inline PlanResult plan_best(const std::vector<GateRec> &queue, int nloc, uint64_
       forced.set_tiles(tiles);
       t.pr = forced.plan(queue);
       t.planned = t.pr.sweeps.size() <= t.K && !plan_has_far_tile(t.pr);     // (the model ignores relabelling and tile positions: check)
-      if (t.planned) t.ms = plan_predicted_ms(t.pr, nloc, bw);
+      // A sharded handle must pick what every other rank picks, and the price is not rank-invariant (a gate that is a ghost on this
+      // rank has left the op list it is computed from): there the fewest sweeps win, ties by the order of the task list.
+      if (t.planned) t.ms = keep_ghosts ? 1000.0 * (double)t.pr.sweeps.size() + 1e-3 * (double)(i + 1) : plan_predicted_ms(t.pr, nloc, bw);
     };
     PlanResult greedy_plan;
     if (tasks.empty() || !env_flag("QH_PLAN_SEARCH_THREADS", true)) {
@@ -2229,7 +2231,7 @@ inline PlanResult plan_best(const std::vector<GateRec> &queue, int nloc, uint64_
     // every task is deterministic by itself (its generator, its budget in label changes); the winner is the plan with the
     // smallest predicted time, ties by the order of the task list -- whatever the threads' timing was
     const Task *win = nullptr;
-    double best_ms = plan_predicted_ms(greedy_plan, nloc, bw);
+    double best_ms = keep_ghosts ? 1000.0 * (double)greedy_plan.sweeps.size() : plan_predicted_ms(greedy_plan, nloc, bw);
     for (const Task &t : tasks)
       if (t.planned && t.pr.sweeps.size() <= greedy_plan.sweeps.size() && t.ms < best_ms) { win = &t; best_ms = t.ms; }
     if (const int pick = env_int("QH_PLAN_SEARCH_PICK", -1); pick >= 0) {      // (probe: the pick-th task of the list, if it has a plan -- tools/probes/r06_candidates.sh)

@@ -230,6 +230,48 @@ def test_every_rank_plans_the_same_geometry(oracle, monkeypatch, env):
     assert err < 1e-11, (env, case, n, gshard, err)
 
 
+def test_searched_plans_are_rank_invariant(oracle, monkeypatch):
+  """plan_best picks among the candidates of its search by a predicted time that depends on the ops a rank really executes
+  -- a gate that is a ghost on this rank has left the op list -- so a sharded handle must choose by something every rank sees
+  alike (fewest sweeps, task order).  Layered circuits (the supremacy family: the search finds several tilings) over 18-20
+  qubits on 4 ranks, with extra dense gates under shard-bit controls (live on some ranks, ghosts on others): identical
+  geometry on every shard, right amplitudes."""
+  monkeypatch.setenv('QH_PLAN_SEARCH_STEPS', '400000')
+  monkeypatch.setenv('QH_PLAN_SEARCH_STREAMS', '6')
+  rng = np.random.default_rng(2606)
+  searched = 0
+  for case, (n, seed) in enumerate(((18, 0), (19, 1), (20, 2), (18, 3))):
+    gshard = 2
+    nloc = n - gshard
+    sops, sg = workloads.supremacy_stream(nloc, 20, seed=seed).arrays()     # the layered circuit on the LOCAL qubits gshard .. n-1
+    stream = [([] if c == NO_CTL else [int(c) + gshard], int(t) + gshard, g.view(np.complex128).reshape(2, 2).copy()) for (c, t), g in zip(sops, sg)]
+    # rank-dependent dense gates: random unitaries on local qubits under a control on a shard qubit (qubits 0, 1 are the shard bits)
+    for k in range(48):
+      q, _ = np.linalg.qr(rng.standard_normal((2, 2)) + 1j * rng.standard_normal((2, 2)))
+      stream.insert(int(rng.integers(30, len(stream))), ([int(rng.integers(0, gshard))], int(rng.integers(gshard, n)), q))
+    psi = rng.standard_normal(1 << n) + 1j * rng.standard_normal(1 << n)
+    psi = (psi / np.linalg.norm(psi)).astype(np.complex128)
+    want = psi.copy()
+    _oracle_apply(oracle, want, n, stream)
+    got = np.empty_like(psi)
+    ref_geom = None
+    monkeypatch.setenv('QH_PLAN_SEARCH', '0')
+    greedy = len(_planned(n, nloc, 0, stream))
+    monkeypatch.setenv('QH_PLAN_SEARCH', '1')
+    for shard in range(1 << gshard):
+      sweeps = _planned(n, nloc, shard, stream)
+      geom = [[(k, sp[k]) for k in GEOMETRY_KEYS] for sp in sweeps]
+      if ref_geom is None:
+        ref_geom = geom
+        searched += len(sweeps) < greedy
+      assert geom == ref_geom, (case, shard, 'the ranks would disagree about an exchange')
+      part = psi[shard << nloc: (shard + 1) << nloc].copy()
+      plan_interp.run_plan(part, sweeps, nloc, shard)
+      got[shard << nloc: (shard + 1) << nloc] = part
+    assert float(np.max(np.abs(got - want))) < 1e-11, (case, n)
+  assert searched >= 1, 'no case in which the search changed the plan: the test does not test what it is for'
+
+
 def test_level_search_saves_sweeps_and_keeps_the_amplitudes(oracle, monkeypatch):
   """planner.h search_levels: for layered circuits the greedy tile choice is not the best one; a budgeted local search over the
   nested cuts of the circuit (deterministic, counted in label changes, a portfolio of host threads) looks for fewer sweeps.
