@@ -2152,10 +2152,11 @@ inline PlanResult plan_best(const std::vector<GateRec> &queue, int nloc, uint64_
   // per task, so the wall time is ONE budget whatever fails (the search for the K that does not exist always does).  A task
   // that finds tiles builds its plan and prices it (plan_predicted_ms: stream energy + op energy under the socket's power
   // limit); the cheapest plan wins -- tilings of one circuit differ by 5-10 % in what their ops cost --, the greedy plan
-  // included.  Every task is deterministic by itself, so the outcome does not depend on the threads' timing.  Twelve
-  // supremacy-30 instances (seeds 0-11): greedy 5 6 6 6 7 7 6 6 5 6 6 6 sweeps, the tile search 4 4 5 5 5 6 5 5 4 5 5 5, now
-  // 4 4 4 4 5 5 4 4 4 4 5 4 (an integer program: 4 is feasible for all but seeds 5 and 10; seed 4 is the one the budget
-  // misses; profiles/r06/level_search.txt); GPU time of the sweeps -6 % on average, -19 % at best.
+  // included (a sharded handle: fewest sweeps, then task order -- see below).  Every task is deterministic by itself, so the
+  // outcome does not depend on the threads' timing.  24 supremacy-30 instances (seeds 0-23): greedy 5-8 sweeps, the tile
+  // search 4 4 5 5 5 6 5 5 4 5 5 5 ..., now 4 4 4 4 4 5 4 4 4 4 5 4 4 4 4 4 4 5 4 5 4 4 4 5 -- for every one the minimum an integer
+  // program finds under 13-bit tiles (tools/tiling_milp.py); GPU time per circuit, old library against new on one box: 32.8 ->
+  // 29.8 ms on average, -19 % at best (profiles/r06/level_search.txt).
   uint64_t dense_bits = 0;
   for (const GateRec &q : queue) if (q.tgt >= 0 && q.tgt < nloc && !plan_diag(q.g, q.tgt)) dense_bits |= 1ull << q.tgt;
   const int lane_low = bw == 128 ? 3 : 4;
