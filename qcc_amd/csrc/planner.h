@@ -538,7 +538,6 @@ class Planner {
     std::vector<long> tabu((size_t)ng * 2);
     std::vector<int> cands;
     bool found = false;
-    int best_over_ever = 1 << 30;
     for (long walk = 0; !found; ++walk) {
       init();
       std::fill(tabu.begin(), tabu.end(), -1);
@@ -546,7 +545,7 @@ class Planner {
       long best_key = cost(&best_over);
       over = best_over;
       for (long it = 0; it < kRestart && over > 0; ++it) {
-        if (changes > change_budget) goto out;
+        if (++changes > change_budget) goto out;       // (an iteration counts as a change: the budget runs out whatever the moves do)
         // a circuit without a K-sweep tiling shows it early (supremacy-30 with K = 3: the overflow never drops below 5; every
         // instance that has one is at 1-4 after 400 iterations): the first walk ends the search then
         if (walk == 0 && it == 400 && best_over > 4) goto out;
@@ -581,7 +580,6 @@ class Planner {
         for (const auto &u : undo) tabu[(size_t)u.first * 2 + ((bm & 1) ? 0 : 1)] = it + kTenure + (long)rnd(kTenure);
         if (k < best_key) { best_key = k; best_over = over; }
       }
-      best_over_ever = std::min(best_over_ever, best_over);
       found = over == 0;
     }
   out:
