@@ -406,7 +406,12 @@ def config_line(name, n, bw, ops, g8, init, device_index, steps, warmup, note, t
     return {'workload': name, 'qubits': n, 'error': str(e)}
   launches = max(1, st['kernels_launched'])
   bytes_l = st['bytes_swept'] / launches
-  ms_l = ev_ms / launches
+  ms_region = ev_ms / launches
+  # The kernel's launch duration: the MEDIAN step's HIP-event time / launches per step.  The mean over the timed region also holds the
+  # idle stretch in front of the first timed step's launches (its planning has no GPU work to hide behind: ~18 ms for a circuit the
+  # planner searches, first_step_ms), which is host time, not kernel time -- rocprofv3's per-dispatch mean (profiles/) agrees with
+  # the median-based figure; the region's mean stays in the line beside it.
+  ms_l = float(np.median(st['step_ms'])) / (launches / steps) if st['step_ms'] else ms_region
   traffic, tsrc = pmc_traffic('k_sweep', True, traffic_file) if traffic_file else (None, None)
   return {'workload': name, 'qubits': n, 'dtype': 'f64' if bw == 128 else 'f32', 'gates_per_step': len(ops), 'steps': steps,
           'warmup': warmup, 'ms_per_step': wall / steps * 1e3,
@@ -418,6 +423,7 @@ def config_line(name, n, bw, ops, g8, init, device_index, steps, warmup, note, t
           'effective_GBps_algorithmic': st['bytes_algorithmic'] / wall / 1e9,
           'roofline': {'bound': 'hbm', 'kernel': 'k_sweep', 'achieved': bytes_l / (ms_l * 1e-3) / 1e9, 'peak': HBM_PEAK_GBPS,
                        'unit': 'GB/s', 'frac': bytes_l / (ms_l * 1e-3) / 1e9 / HBM_PEAK_GBPS, 'avg_launch_ms': ms_l,
+                       'avg_launch_ms_source': 'median step (HIP events) / launches per step', 'avg_launch_ms_over_timed_region': ms_region,
                        'bytes_per_launch': bytes_l, 'traffic': traffic, 'traffic_source': tsrc},
           'norm2': norm2, 'note': note}
 
